@@ -1,0 +1,127 @@
+"""Pin oracle/ against the golden vectors generated from the reference (CPU only)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import loss_oracle, metrics_oracle, optim_oracle, unet_oracle
+
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def _load(name):
+    return np.load(os.path.join(GOLDEN, name + '.npz'))
+
+
+def _sd(z, prefix):
+    return {k[len(prefix):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(prefix)}
+
+
+@pytest.mark.parametrize('name,netG', [('unet256_ngf4', 'unet_256'), ('unet128_ngf4_dn', 'unet_128')])
+def test_unet_forward_backward_matches_reference(name, netG):
+    z = _load(name)
+    ngf, S, depth_norm, B = [int(v) for v in z['meta']]
+    lr, max_depth, l1w, sw, lam = [float(v) for v in z['hyper']]
+    nd = unet_oracle.num_downs_of(netG)
+    sd = _sd(z, 'sd0/')
+    audio, gt = torch.from_numpy(z['audio']), torch.from_numpy(z['gt'])
+
+    # eval-mode forward
+    with torch.no_grad():
+        pe, _ = unet_oracle.unet_forward(sd, audio, nd, bool(depth_norm), training=False)
+    np.testing.assert_allclose(pe.numpy(), z['pred_eval'], rtol=1e-5, atol=1e-6)
+
+    # train-mode forward + loss + backward
+    pkeys = unet_oracle.param_keys(nd)
+    assert pkeys == [k[len('grad/'):] for k in z.files if k.startswith('grad/')]
+    for k in pkeys:
+        sd[k] = sd[k].clone().requires_grad_(True)
+    pred, new_stats = unet_oracle.unet_forward(sd, audio, nd, bool(depth_norm), training=True)
+    np.testing.assert_allclose(pred.detach().numpy(), z['pred_train'], rtol=1e-5, atol=1e-6)
+    scale = max_depth if depth_norm else 1.0
+    loss = loss_oracle.masked_loss(pred, gt, 'Combined', l1w, sw, lam, scale=scale)
+    assert abs(loss.item() - float(z['loss'])) <= 1e-5 * abs(float(z['loss']))
+    loss.backward()
+    for k in pkeys:
+        ref = z['grad/' + k]
+        got = sd[k].grad.numpy()
+        np.testing.assert_allclose(got, ref, rtol=2e-3, atol=1e-6 + 1e-4 * np.abs(ref).max())
+    for k, v in new_stats.items():
+        np.testing.assert_allclose(v.numpy(), z['sd1/' + k], rtol=1e-5, atol=1e-6)
+
+    # clip + AdamW
+    grads = [sd[k].grad.numpy() for k in pkeys]
+    total, coef = optim_oracle.clip_coef(grads, 1.0)
+    assert abs(total - float(z['grad_norm'])) <= 1e-4 * float(z['grad_norm'])
+    for k in pkeys:
+        p1, _, _ = optim_oracle.adamw_step(sd[k].detach().numpy(), sd[k].grad.numpy(),
+                                           np.zeros(sd[k].shape), np.zeros(sd[k].shape), 1, lr,
+                                           grad_scale=coef)
+        np.testing.assert_allclose(p1, z['sd1/' + k], rtol=1e-4, atol=2e-6)
+
+
+def test_param_key_layout_unet256():
+    keys = unet_oracle.param_keys(8)
+    assert len(keys) == 43
+    assert keys[0] == 'model.model.0.weight'
+    assert keys[-2:] == ['model.model.3.weight', 'model.model.3.bias']
+    chans = unet_oracle.level_channels(8, 64, 2, 1)
+    assert chans[0] == (2, 64, 128, 1) and chans[7] == (512, 512, 512, 512) and chans[3] == (256, 512, 1024, 256)
+
+
+def test_conv_definitions_pin_torch_ops():
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(2, 3, 8, 8)).astype(np.float32)
+    w = rng.normal(size=(5, 3, 4, 4)).astype(np.float32)
+    y = torch.nn.functional.conv2d(torch.from_numpy(x), torch.from_numpy(w), stride=2, padding=1).numpy()
+    np.testing.assert_allclose(y, unet_oracle.conv2d_direct_numpy(x, w, 2, 1), rtol=1e-4, atol=1e-4)
+    wt = rng.normal(size=(3, 5, 4, 4)).astype(np.float32)
+    yt = torch.nn.functional.conv_transpose2d(torch.from_numpy(x), torch.from_numpy(wt), stride=2, padding=1).numpy()
+    np.testing.assert_allclose(yt, unet_oracle.conv_transpose2d_direct_numpy(x, wt, 2, 1), rtol=1e-4, atol=1e-4)
+
+
+def test_loss_cases():
+    z = _load('loss_cases')
+    pred, gt = z['pred'], z['gt']
+    for lam in (0.5, 0.869, 1.0):
+        v = loss_oracle.masked_loss(torch.from_numpy(pred), torch.from_numpy(gt), 'SIlog', silog_lambda=lam)
+        assert abs(v.item() - float(z[f'silog_{lam}'])) < 1e-5
+        g = loss_oracle.masked_loss_grad_numpy(pred, gt, 'SIlog', silog_lambda=lam)
+        np.testing.assert_allclose(g, z[f'silog_grad_{lam}'], rtol=1e-3, atol=1e-8)
+    g = loss_oracle.masked_loss_grad_numpy(pred, gt, 'Combined', 0.237, 0.637, 0.869)
+    np.testing.assert_allclose(g, z['combined_grad'], rtol=1e-3, atol=1e-8)
+    v = loss_oracle.masked_loss(torch.from_numpy(pred), torch.from_numpy(gt), 'Combined', 0.237, 0.637, 0.869)
+    assert abs(v.item() - float(z['combined'])) < 1e-5
+
+
+def test_metrics_cases():
+    z = _load('metrics_cases')
+    names = sorted({k.split('/')[0] for k in z.files})
+    assert 'pred_all_negative' in names and 'batched' in names
+    for n in names:
+        got = metrics_oracle.compute_errors(z[n + '/gt'], z[n + '/pred'])
+        np.testing.assert_allclose(np.array(got, dtype=np.float64), z[n + '/ref'], rtol=1e-6, atol=1e-7,
+                                   err_msg=n)
+
+
+@pytest.mark.parametrize('opt', ['AdamW', 'Adam', 'SGD', 'Adam_wd'])
+def test_optim_cases(opt):
+    z = _load('optim_cases')
+    ps = [z[f'{opt}/p0/{i}'].astype(np.float64) for i in range(3)]
+    ms = [np.zeros_like(p) for p in ps]
+    vs = [np.zeros_like(p) for p in ps]
+    for step in range(3):
+        gs = [z[f'{opt}/g{step}/{i}'] for i in range(3)]
+        total, coef = optim_oracle.clip_coef(gs, 1.0)
+        assert abs(total - float(z[f'{opt}/norm{step}'])) < 1e-4 * total
+        for i in range(3):
+            if opt == 'SGD':
+                ps[i] = optim_oracle.sgd_step(ps[i], gs[i], 0.002, coef)
+            else:
+                lr = 0.001 if opt == 'Adam_wd' else 0.002
+                wd = {'AdamW': 0.01, 'Adam': 0.0, 'Adam_wd': 0.01}[opt]
+                ps[i], ms[i], vs[i] = optim_oracle.adamw_step(ps[i], gs[i], ms[i], vs[i], step + 1, lr,
+                                                               weight_decay=wd, decoupled=(opt == 'AdamW'),
+                                                               grad_scale=coef)
+            np.testing.assert_allclose(ps[i], z[f'{opt}/p{step + 1}/{i}'], rtol=2e-5, atol=2e-6)
