@@ -1,0 +1,130 @@
+"""ctypes binding of libadn.so (the C ABI declared in include/adn.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, a
+RuntimeError is raised.  Build with ``make -C audio-depth-estimation_amd/csrc`` (or
+``__graft_entry__.build()``); the .so is kept in-tree next to this file.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libadn.so')
+
+ADN_F32, ADN_BF16 = 0, 1
+GEMM_S2, GEMM_T2 = 0, 1
+EPI_RAW, EPI_Z_STATS, EPI_ACT, EPI_BWD, EPI_FINAL = 0, 1, 2, 3, 4
+
+c_void_p, c_int32, c_int64, c_float = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class AdnEpiSeg(C.Structure):
+    _fields_ = [
+        ('out0', c_void_p), ('out1', c_void_p), ('ref', c_void_p), ('z', c_void_p),
+        ('mean', c_void_p), ('istd', c_void_p), ('scale', c_void_p), ('shift', c_void_p),
+        ('bias', c_void_p), ('partials', c_void_p),
+        ('channels', c_int32), ('slope', c_float), ('accumulate', c_int32), ('final_act', c_int32),
+    ]
+
+
+class AdnIgemmDesc(C.Structure):
+    _fields_ = [
+        ('dtype', c_int32), ('geom', c_int32), ('B', c_int32), ('Hs', c_int32), ('Ws', c_int32),
+        ('C0', c_int32), ('C1', c_int32), ('N', c_int32),
+        ('in0', c_void_p), ('in1', c_void_p), ('w', c_void_p),
+        ('epi', c_int32), ('seg', AdnEpiSeg * 2),
+        ('workspace', c_void_p), ('workspace_bytes', c_int64),
+    ]
+
+
+class AdnWgradDesc(C.Structure):
+    _fields_ = [
+        ('dtype', c_int32), ('B', c_int32), ('Hs', c_int32), ('Ws', c_int32),
+        ('plain0', c_void_p), ('plain1', c_void_p), ('R0', c_int32), ('R1', c_int32),
+        ('gath0', c_void_p), ('gath1', c_void_p), ('C0', c_int32), ('C1', c_int32),
+        ('dw', c_void_p), ('workspace', c_void_p), ('workspace_bytes', c_int64),
+    ]
+
+
+# name -> (restype, argtypes).  Must list every symbol include/adn.h declares
+# (tests/test_abi.py cross-checks this table against the header and the built library).
+_PROTOS = {
+    'adn_last_error': (C.c_char_p, []),
+    'adn_version': (C.c_int, []),
+    'adn_igemm_num_partials': (c_int64, [C.POINTER(AdnIgemmDesc)]),
+    'adn_igemm_workspace_bytes': (c_int64, [C.POINTER(AdnIgemmDesc)]),
+    'adn_igemm': (C.c_int, [C.POINTER(AdnIgemmDesc), c_void_p]),
+    'adn_wgrad_workspace_bytes': (c_int64, [C.POINTER(AdnWgradDesc)]),
+    'adn_wgrad': (C.c_int, [C.POINTER(AdnWgradDesc), c_void_p]),
+    'adn_pack_weights': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    'adn_nchw_to_nhwc': (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    'adn_nhwc_to_nchw': (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    'adn_bn_fwd_finalize': (C.c_int, [c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p, c_float, c_float,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p]),
+    'adn_bn_eval_affine': (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int32, c_void_p, c_void_p,
+                                     c_void_p]),
+    'adn_bn_act': (C.c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                             c_void_p]),
+    'adn_bn_bwd_finalize': (C.c_int, [c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'adn_bn_bwd_apply': (C.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p]),
+    'adn_loss_stats': (C.c_int, [c_void_p, c_void_p, c_int64, c_float, c_int32, c_float, c_void_p, c_void_p,
+                                 c_int64, c_void_p]),
+    'adn_loss_workspace_bytes': (c_int64, [c_int64]),
+    'adn_loss_finish': (C.c_int, [c_void_p, c_void_p, c_int64, c_float, c_int32, c_float, c_void_p, c_int32,
+                                  c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    'adn_final_act_bwd': (C.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
+    'adn_sum_to_scalar': (C.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
+    'adn_grad_norm': (C.c_int, [c_void_p, c_int64, c_float, c_void_p, c_void_p, c_int64, c_void_p]),
+    'adn_grad_norm_workspace_bytes': (c_int64, [c_int64]),
+    'adn_optimizer_step': (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_float,
+                                     c_float, c_float, c_float, c_int32, c_void_p, c_void_p]),
+    'adn_compute_errors': (C.c_int, [c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
+    'adn_compute_errors_workspace_bytes': (c_int64, [c_int32, c_int64]),
+    'adn_frontend_workspace_bytes': (c_int64, [c_int32, c_int32, c_int32]),
+    'adn_frontend': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int64,
+                               c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libadn.so once; raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f'libadn.so not found at {LIB_PATH}: the HIP extension is not built. '
+            'Run `make -C audio-depth-estimation_amd/csrc` or `python -c "import __graft_entry__ as g; g.build()"`. '
+            'There is no CPU fallback for the product path.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def symbol_names():
+    return sorted(_PROTOS)
+
+
+def check(rc: int, what: str = ''):
+    if rc != 0:
+        msg = load().adn_last_error().decode('utf-8', 'replace')
+        raise RuntimeError(f'libadn {what} failed (rc={rc}): {msg}')
+
+
+def call(name: str, *args):
+    """Call an int-returning entry point and raise on error."""
+    check(getattr(load(), name)(*args), name)
+
+
+def ptr(t):
+    """Device/host pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()

@@ -1,0 +1,305 @@
+// Memory-bound helpers around the implicit GEMMs: weight packing, NCHW<->NHWC boundary
+// conversion, BatchNorm finalize / apply passes.  All are streaming kernels (HBM roofline),
+// 16-byte accesses where the layout allows, grid capped at ~2048 blocks with grid-stride loops.
+#include "epilogue.h"
+
+namespace {
+
+constexpr int kMaxBlocks = 4096;
+inline unsigned blocks_for(int64_t n, int per_block = 256) {
+  int64_t b = adn_cdiv(n, per_block);
+  if (b > kMaxBlocks) b = kMaxBlocks;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+// master [X][4][4][Y] f32 -> s2 [X][16][Y] (cast), t2 [4][Y][4][X] (phase split)
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* master, int X, int Y, T* s2, T* t2) {
+  const int64_t n = (int64_t)X * 16 * Y;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    if (s2) ElemTraits<T>::store(s2 + e, master[e]);
+    if (t2) {
+      // destination-ordered: e -> (phase, y, t, x)
+      const int x = (int)(e % X);
+      const int t = (int)((e / X) % 4);
+      const int y = (int)((e / ((int64_t)4 * X)) % Y);
+      const int phase = (int)(e / ((int64_t)4 * X * Y));
+      const int kh = adn_t2_kh(phase >> 1, t >> 1), kw = adn_t2_kh(phase & 1, t & 1);
+      ElemTraits<T>::store(t2 + e, master[(((int64_t)x * 4 + kh) * 4 + kw) * Y + y]);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* src, T* dst, int B, int C, int64_t HW) {
+  const int64_t n = (int64_t)B * C * HW;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const int c = (int)(e % C);
+    const int64_t pix = e / C;
+    const int64_t b = pix / HW, hw = pix - b * HW;
+    ElemTraits<T>::store(dst + e, src[(b * C + c) * HW + hw]);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* src, float* dst, int B, int C, int64_t HW) {
+  const int64_t n = (int64_t)B * C * HW;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const int64_t hw = e % HW;
+    const int64_t bc = e / HW;
+    const int c = (int)(bc % C);
+    const int64_t b = bc / C;
+    dst[e] = ElemTraits<T>::load(src + (b * HW + hw) * C + c);
+  }
+}
+
+// one wave per channel: sum partial rows in f64
+__global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const float* partials, int64_t P, int C, double count,
+                                                              const float* gamma, const float* beta, float eps,
+                                                              float momentum, float* rmean, float* rvar,
+                                                              int64_t* nbt, float* mean, float* istd, float* scale,
+                                                              float* shift) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int64_t r = lane; r < P; r += 64) {
+    s1 += (double)partials[(r * 2 + 0) * C + c];
+    s2 += (double)partials[(r * 2 + 1) * C + c];
+  }
+  s1 = wave_sum_d(s1);
+  s2 = wave_sum_d(s2);
+  if (lane == 0) {
+    const double mu = s1 / count;
+    double var = s2 / count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const double is = 1.0 / sqrt(var + (double)eps);
+    const double g = gamma ? (double)gamma[c] : 1.0, b = beta ? (double)beta[c] : 0.0;
+    mean[c] = (float)mu;
+    istd[c] = (float)is;
+    scale[c] = (float)(g * is);
+    shift[c] = (float)(b - mu * g * is);
+    if (rmean) {
+      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      rmean[c] = (float)((1.0 - momentum) * (double)rmean[c] + momentum * mu);
+      rvar[c] = (float)((1.0 - momentum) * (double)rvar[c] + momentum * unbiased);
+    }
+    if (nbt && c == 0) nbt[0] += 1;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* rm,
+                                                             const float* rv, float eps, int C, float* scale,
+                                                             float* shift) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float is = 1.0f / sqrtf(rv[c] + eps);
+  const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
+  scale[c] = g * is;
+  shift[c] = b - rm[c] * g * is;
+}
+
+// y = z*scale+shift -> leaky / relu copies.  8 channels (one or two 16-byte chunks) per thread.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_kernel(const T* z, int64_t pixels, int C, const float* scale,
+                                                     const float* shift, float slope, T* out_leaky, T* out_relu) {
+  const int64_t n = pixels * C;
+  if ((C & 7) == 0) {
+    const int64_t groups = n >> 3;
+    for (int64_t gidx = (int64_t)blockIdx.x * 256 + threadIdx.x; gidx < groups; gidx += (int64_t)gridDim.x * 256) {
+      const int64_t e = gidx << 3;
+      const int c = (int)(e % C);
+      float v[8], o[8];
+      load8<T>(z, e, v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = v[k] * scale[c + k] + shift[c + k];
+      if (out_leaky) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = v[k] > 0.f ? v[k] : v[k] * slope;
+        store8<T>(out_leaky, e, o);
+      }
+      if (out_relu) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = fmaxf(v[k], 0.f);
+        store8<T>(out_relu, e, o);
+      }
+    }
+  } else {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+      const int c = (int)(e % C);
+      const float y = ElemTraits<T>::load(z + e) * scale[c] + shift[c];
+      if (out_leaky) ElemTraits<T>::store(out_leaky + e, y > 0.f ? y : y * slope);
+      if (out_relu) ElemTraits<T>::store(out_relu + e, fmaxf(y, 0.f));
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* partials, int64_t P, int C, double count,
+                                                              float* dgamma, float* dbeta, float* coef) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int64_t r = lane; r < P; r += 64) {
+    s1 += (double)partials[(r * 2 + 0) * C + c];
+    s2 += (double)partials[(r * 2 + 1) * C + c];
+  }
+  s1 = wave_sum_d(s1);
+  s2 = wave_sum_d(s2);
+  if (lane == 0) {
+    if (dbeta) dbeta[c] = (float)s1;
+    if (dgamma) dgamma[c] = (float)s2;
+    coef[c] = (float)(s1 / count);
+    coef[C + c] = (float)(s2 / count);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(T* g, const T* z, int64_t pixels, int C,
+                                                           const float* scale, const float* mean, const float* istd,
+                                                           const float* coef) {
+  const int64_t n = pixels * C;
+  if ((C & 7) == 0) {
+    const int64_t groups = n >> 3;
+    for (int64_t gidx = (int64_t)blockIdx.x * 256 + threadIdx.x; gidx < groups; gidx += (int64_t)gridDim.x * 256) {
+      const int64_t e = gidx << 3;
+      const int c = (int)(e % C);
+      float gv[8], zv[8];
+      load8<T>(g, e, gv);
+      load8<T>(z, e, zv);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float xh = (zv[k] - mean[c + k]) * istd[c + k];
+        gv[k] = scale[c + k] * (gv[k] - coef[c + k] - xh * coef[C + c + k]);
+      }
+      store8<T>(g, e, gv);
+    }
+  } else {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+      const int c = (int)(e % C);
+      const float xh = (ElemTraits<T>::load(z + e) - mean[c]) * istd[c];
+      ElemTraits<T>::store(g + e, scale[c] * (ElemTraits<T>::load(g + e) - coef[c] - xh * coef[C + c]));
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int adn_pack_weights(const float* master, int32_t X, int32_t Y, int32_t dtype, void* s2_out,
+                                void* t2_out, void* stream) {
+  ADN_CHECK_ARG(master && X > 0 && Y > 0, "adn_pack_weights: bad arguments");
+  ADN_CHECK_ARG(dtype == ADN_F32 || dtype == ADN_BF16, "adn_pack_weights: bad dtype %d", dtype);
+  ADN_CHECK_ARG(s2_out || t2_out, "adn_pack_weights: no output");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int64_t n = (int64_t)X * 16 * Y;
+  if (dtype == ADN_BF16)
+    hipLaunchKernelGGL((pack_weights_kernel<uint16_t>), dim3(blocks_for(n)), dim3(256), 0, st, master, X, Y,
+                       reinterpret_cast<uint16_t*>(s2_out), reinterpret_cast<uint16_t*>(t2_out));
+  else
+    hipLaunchKernelGGL((pack_weights_kernel<float>), dim3(blocks_for(n)), dim3(256), 0, st, master, X, Y,
+                       reinterpret_cast<float*>(s2_out), reinterpret_cast<float*>(t2_out));
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}
+
+extern "C" int adn_nchw_to_nhwc(const float* src, void* dst, int32_t B, int32_t C, int32_t H, int32_t W,
+                                int32_t dtype, void* stream) {
+  ADN_CHECK_ARG(src && dst && B > 0 && C > 0 && H > 0 && W > 0, "adn_nchw_to_nhwc: bad arguments");
+  ADN_CHECK_ARG(dtype == ADN_F32 || dtype == ADN_BF16, "adn_nchw_to_nhwc: bad dtype %d", dtype);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int64_t n = (int64_t)B * C * H * W;
+  if (dtype == ADN_BF16)
+    hipLaunchKernelGGL((nchw_to_nhwc_kernel<uint16_t>), dim3(blocks_for(n)), dim3(256), 0, st, src,
+                       reinterpret_cast<uint16_t*>(dst), B, C, (int64_t)H * W);
+  else
+    hipLaunchKernelGGL((nchw_to_nhwc_kernel<float>), dim3(blocks_for(n)), dim3(256), 0, st, src,
+                       reinterpret_cast<float*>(dst), B, C, (int64_t)H * W);
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}
+
+extern "C" int adn_nhwc_to_nchw(const void* src, float* dst, int32_t B, int32_t C, int32_t H, int32_t W,
+                                int32_t dtype, void* stream) {
+  ADN_CHECK_ARG(src && dst && B > 0 && C > 0 && H > 0 && W > 0, "adn_nhwc_to_nchw: bad arguments");
+  ADN_CHECK_ARG(dtype == ADN_F32 || dtype == ADN_BF16, "adn_nhwc_to_nchw: bad dtype %d", dtype);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int64_t n = (int64_t)B * C * H * W;
+  if (dtype == ADN_BF16)
+    hipLaunchKernelGGL((nhwc_to_nchw_kernel<uint16_t>), dim3(blocks_for(n)), dim3(256), 0, st,
+                       reinterpret_cast<const uint16_t*>(src), dst, B, C, (int64_t)H * W);
+  else
+    hipLaunchKernelGGL((nhwc_to_nchw_kernel<float>), dim3(blocks_for(n)), dim3(256), 0, st,
+                       reinterpret_cast<const float*>(src), dst, B, C, (int64_t)H * W);
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}
+
+extern "C" int adn_bn_fwd_finalize(const float* partials, int64_t P, int32_t C, int64_t count, const float* gamma,
+                                   const float* beta, float eps, float momentum, float* running_mean,
+                                   float* running_var, int64_t* num_batches_tracked, float* mean, float* istd,
+                                   float* scale, float* shift, void* stream) {
+  ADN_CHECK_ARG(partials && P > 0 && C > 0 && count > 0 && mean && istd && scale && shift,
+                "adn_bn_fwd_finalize: bad arguments");
+  ADN_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "adn_bn_fwd_finalize: running stats mismatch");
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((unsigned)adn_cdiv(C, 4)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), partials, P, C, (double)count, gamma, beta, eps, momentum,
+                     running_mean, running_var, num_batches_tracked, mean, istd, scale, shift);
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}
+
+extern "C" int adn_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                                  const float* running_var, float eps, int32_t C, float* scale, float* shift,
+                                  void* stream) {
+  ADN_CHECK_ARG(running_mean && running_var && scale && shift && C > 0, "adn_bn_eval_affine: bad arguments");
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((unsigned)adn_cdiv(C, 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), gamma, beta, running_mean, running_var, eps, C, scale,
+                     shift);
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}
+
+extern "C" int adn_bn_act(const void* z, int64_t pixels, int32_t C, int32_t dtype, const float* scale,
+                          const float* shift, float slope, void* out_leaky, void* out_relu, void* stream) {
+  ADN_CHECK_ARG(z && pixels > 0 && C > 0 && scale && shift && (out_leaky || out_relu), "adn_bn_act: bad arguments");
+  ADN_CHECK_ARG(dtype == ADN_F32 || dtype == ADN_BF16, "adn_bn_act: bad dtype %d", dtype);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int64_t work = (C & 7) == 0 ? pixels * C / 8 : pixels * C;
+  if (dtype == ADN_BF16)
+    hipLaunchKernelGGL((bn_act_kernel<uint16_t>), dim3(blocks_for(work)), dim3(256), 0, st,
+                       reinterpret_cast<const uint16_t*>(z), pixels, C, scale, shift, slope,
+                       reinterpret_cast<uint16_t*>(out_leaky), reinterpret_cast<uint16_t*>(out_relu));
+  else
+    hipLaunchKernelGGL((bn_act_kernel<float>), dim3(blocks_for(work)), dim3(256), 0, st,
+                       reinterpret_cast<const float*>(z), pixels, C, scale, shift, slope,
+                       reinterpret_cast<float*>(out_leaky), reinterpret_cast<float*>(out_relu));
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}
+
+extern "C" int adn_bn_bwd_finalize(const float* partials, int64_t P, int32_t C, int64_t count, float* dgamma,
+                                   float* dbeta, float* coef, void* stream) {
+  ADN_CHECK_ARG(partials && P > 0 && C > 0 && count > 0 && coef, "adn_bn_bwd_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)adn_cdiv(C, 4)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), partials, P, C, (double)count, dgamma, dbeta, coef);
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}
+
+extern "C" int adn_bn_bwd_apply(void* g, const void* z, int64_t pixels, int32_t C, int32_t dtype, const float* scale,
+                                const float* mean, const float* istd, const float* coef, void* stream) {
+  ADN_CHECK_ARG(g && z && pixels > 0 && C > 0 && scale && mean && istd && coef, "adn_bn_bwd_apply: bad arguments");
+  ADN_CHECK_ARG(dtype == ADN_F32 || dtype == ADN_BF16, "adn_bn_bwd_apply: bad dtype %d", dtype);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int64_t work = (C & 7) == 0 ? pixels * C / 8 : pixels * C;
+  if (dtype == ADN_BF16)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<uint16_t>), dim3(blocks_for(work)), dim3(256), 0, st,
+                       reinterpret_cast<uint16_t*>(g), reinterpret_cast<const uint16_t*>(z), pixels, C, scale, mean,
+                       istd, coef);
+  else
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(blocks_for(work)), dim3(256), 0, st,
+                       reinterpret_cast<float*>(g), reinterpret_cast<const float*>(z), pixels, C, scale, mean, istd,
+                       coef);
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}

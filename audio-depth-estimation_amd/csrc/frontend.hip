@@ -1,0 +1,232 @@
+// Audio front-end on device: centred reflect-padded STFT magnitude (n_fft 512, periodic Hann(64),
+// hop 16 or 32) as a 64-tap windowed DFT, optional HTK mel projection (257 -> 32), log + per-channel
+// min-max, bilinear resize (align_corners=False, optional antialias) to S x S.
+// Follows SURVEY.md Appendix B; reference call sites: dataloader/BatvisionV2_Dataset.py:94-135,
+// :177-197, dataloader/BatvisionV1_Dataset.py:68-95, dataloader/utils_dataset.py:18-20.
+//
+// Workspace layout (floats): basis_cos[257*64] | basis_sin[257*64] | fb[257*32] |
+//                            spec[B*2*F*nT] | minmax partials [B*2*tiles*2]
+#include "adn_common.h"
+
+namespace {
+
+constexpr int NFFT = 512, WIN = 64, NBIN = 257, NMEL = 32, PAD = 256, OFF = 224;
+constexpr int FT = 8;  // frames per block
+
+__global__ __launch_bounds__(256) void fe_tables_kernel(float* bcos, float* bsin, float* fb) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx < NBIN * WIN) {
+    const int k = idx / WIN, j = idx % WIN;
+    const int ph = (k * (OFF + j)) & (NFFT - 1);                  // exact integer phase reduction
+    const double w = 0.5 - 0.5 * cospi(2.0 * (double)j / WIN);    // periodic Hann
+    bcos[idx] = (float)(w * cospi(2.0 * ph / (double)NFFT));
+    bsin[idx] = (float)(-w * sinpi(2.0 * ph / (double)NFFT));
+  }
+  if (idx < NBIN * NMEL) {
+    const int f = idx / NMEL, m = idx % NMEL;
+    auto hz2mel = [](double h) { return 2595.0 * log10(1.0 + h / 700.0); };
+    auto mel2hz = [](double x) { return 700.0 * (pow(10.0, x / 2595.0) - 1.0); };
+    const double mlo = hz2mel(20.0), mhi = hz2mel(20000.0);
+    const double step = (mhi - mlo) / (NMEL + 1);
+    const double f0 = mel2hz(mlo + step * m), f1 = mel2hz(mlo + step * (m + 1)), f2 = mel2hz(mlo + step * (m + 2));
+    const double freq = (double)f * (44100 / 2) / (NBIN - 1);
+    const double down = (freq - f0) / (f1 - f0), up = (f2 - freq) / (f2 - f1);
+    const double v = fmin(down, up);
+    fb[idx] = (float)(v > 0.0 ? v : 0.0);
+  }
+}
+
+__device__ __forceinline__ int reflect(int i, int T) { return i < 0 ? -i : (i >= T ? 2 * (T - 1) - i : i); }
+
+// grid (frame tiles, B*2).  mode 0: mel+log, 1: linear+log, 2: linear raw.
+__global__ __launch_bounds__(256) void fe_stft_kernel(const float* wave, int T, int hop, int nT, int mode,
+                                                      const float* bcos, const float* bsin, const float* fb,
+                                                      float* spec, float* mm_part, int tiles) {
+  __shared__ float fr[FT][WIN];
+  __shared__ float mag[FT][NBIN + 3];
+  __shared__ float red[8];
+  const int bc = blockIdx.y;
+  const int t0 = blockIdx.x * FT;
+  const float* x = wave + (int64_t)bc * T;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < FT * WIN; e += 256) {
+    const int f = e / WIN, j = e % WIN;
+    const int t = t0 + f;
+    fr[f][j] = t < nT ? x[reflect(t * hop + OFF + j - PAD, T)] : 0.f;
+  }
+  __syncthreads();
+  for (int k = tid; k < NBIN; k += 256) {
+    float re[FT], im[FT];
+#pragma unroll
+    for (int f = 0; f < FT; ++f) re[f] = im[f] = 0.f;
+    for (int j = 0; j < WIN; ++j) {
+      const float c = bcos[k * WIN + j], s = bsin[k * WIN + j];
+#pragma unroll
+      for (int f = 0; f < FT; ++f) {
+        re[f] += fr[f][j] * c;
+        im[f] += fr[f][j] * s;
+      }
+    }
+#pragma unroll
+    for (int f = 0; f < FT; ++f) mag[f][k] = sqrtf(re[f] * re[f] + im[f] * im[f]);
+  }
+  __syncthreads();
+  const int F = mode == 0 ? NMEL : NBIN;
+  float lo = INFINITY, hi = -INFINITY;
+  for (int e = tid; e < F * FT; e += 256) {
+    const int f = e % FT, r = e / FT;
+    const int t = t0 + f;
+    if (t >= nT) continue;
+    float v;
+    if (mode == 0) {
+      v = 0.f;
+      for (int k = 0; k < NBIN; ++k) v += mag[f][k] * fb[k * NMEL + r];
+    } else {
+      v = mag[f][r];
+    }
+    if (mode != 2) v = logf(v + 1e-8f);
+    lo = fminf(lo, v);
+    hi = fmaxf(hi, v);
+    spec[((int64_t)bc * F + r) * nT + t] = v;
+  }
+  lo = wave_min(lo);
+  hi = wave_max(hi);
+  if ((tid & 63) == 0) {
+    red[(tid >> 6) * 2] = lo;
+    red[(tid >> 6) * 2 + 1] = hi;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    mm_part[((int64_t)bc * tiles + blockIdx.x) * 2 + 0] = fminf(fminf(red[0], red[2]), fminf(red[4], red[6]));
+    mm_part[((int64_t)bc * tiles + blockIdx.x) * 2 + 1] = fmaxf(fmaxf(red[1], red[3]), fmaxf(red[5], red[7]));
+  }
+}
+
+// separable triangle-filter weights of one output coordinate (ATen upsample_bilinear2d /
+// _upsample_bilinear2d_aa, align_corners=False)
+struct Taps {
+  int start, count;
+  float scale_inv, center, total;
+};
+__device__ __forceinline__ float tap_w(const Taps& t, int j, bool aa, float lerp) {
+  if (!aa) return j == 0 ? 1.0f - lerp : lerp;
+  const float a = fabsf(((float)(j + t.start) - t.center + 0.5f) * t.scale_inv);
+  return a < 1.0f ? 1.0f - a : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void fe_resize_kernel(const float* spec, const float* mm_part, int tiles, int F,
+                                                        int nT, int S, int antialias, int normalise, float* out) {
+  const int bc = blockIdx.y;
+  __shared__ float s_lo, s_hi;
+  if (threadIdx.x == 0) {
+    float lo = INFINITY, hi = -INFINITY;
+    for (int i = 0; i < tiles; ++i) {
+      lo = fminf(lo, mm_part[((int64_t)bc * tiles + i) * 2]);
+      hi = fmaxf(hi, mm_part[((int64_t)bc * tiles + i) * 2 + 1]);
+    }
+    s_lo = lo;
+    s_hi = hi;
+  }
+  __syncthreads();
+  const float lo = s_lo, hi = s_hi;
+  const bool flat = !(hi > lo);
+  const float inv = flat ? 0.f : 1.0f / (hi - lo);
+  const float* src = spec + (int64_t)bc * F * nT;
+  const float sy = (float)F / S, sx = (float)nT / S;
+  const bool aay = antialias && sy > 1.0f, aax = antialias && sx > 1.0f;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < S * S; e += gridDim.x * 256) {
+    const int oy = e / S, ox = e % S;
+    Taps ty, tx;
+    float ly = 0.f, lx = 0.f;
+    if (aay) {
+      const float c = sy * (oy + 0.5f);
+      ty.center = c;
+      ty.scale_inv = 1.0f / sy;
+      ty.start = max((int)(c - sy + 0.5f), 0);
+      ty.count = min((int)(c + sy + 0.5f), F) - ty.start;
+    } else {
+      const float s = fmaxf((oy + 0.5f) * sy - 0.5f, 0.f);
+      const int i0 = min((int)s, F - 1);
+      ty.start = i0;
+      ty.count = 2;
+      ly = s - i0;
+    }
+    if (aax) {
+      const float c = sx * (ox + 0.5f);
+      tx.center = c;
+      tx.scale_inv = 1.0f / sx;
+      tx.start = max((int)(c - sx + 0.5f), 0);
+      tx.count = min((int)(c + sx + 0.5f), nT) - tx.start;
+    } else {
+      const float s = fmaxf((ox + 0.5f) * sx - 0.5f, 0.f);
+      const int i0 = min((int)s, nT - 1);
+      tx.start = i0;
+      tx.count = 2;
+      lx = s - i0;
+    }
+    float wy_tot = 0.f, wx_tot = 0.f;
+    for (int j = 0; j < ty.count; ++j) wy_tot += tap_w(ty, j, aay, ly);
+    for (int j = 0; j < tx.count; ++j) wx_tot += tap_w(tx, j, aax, lx);
+    float acc = 0.f;
+    for (int jy = 0; jy < ty.count; ++jy) {
+      const int iy = min(ty.start + jy, F - 1);
+      const float wy = tap_w(ty, jy, aay, ly) / wy_tot;
+      float row = 0.f;
+      for (int jx = 0; jx < tx.count; ++jx) {
+        const int ix = min(tx.start + jx, nT - 1);
+        float v = src[(int64_t)iy * nT + ix];
+        if (normalise) v = flat ? 0.f : (v - lo) * inv;
+        row += v * (tap_w(tx, jx, aax, lx) / wx_tot);
+      }
+      acc += row * wy;
+    }
+    out[(int64_t)bc * S * S + e] = acc;
+  }
+}
+
+struct FeDims {
+  int hop, nT, F, tiles;
+  int64_t off_cos, off_sin, off_fb, off_spec, off_mm, total;
+};
+FeDims fe_dims(int B, int T, int mode) {
+  FeDims d;
+  d.hop = mode == 0 ? WIN / 2 : WIN / 4;      // mel path passes no hop_length -> win_length//2
+  d.nT = 1 + T / d.hop;
+  d.F = mode == 0 ? NMEL : NBIN;
+  d.tiles = (int)adn_cdiv(d.nT, FT);
+  d.off_cos = 0;
+  d.off_sin = d.off_cos + NBIN * WIN;
+  d.off_fb = d.off_sin + NBIN * WIN;
+  d.off_spec = d.off_fb + NBIN * NMEL;
+  d.off_mm = d.off_spec + (int64_t)B * 2 * d.F * d.nT;
+  d.total = d.off_mm + (int64_t)B * 2 * d.tiles * 2;
+  return d;
+}
+
+}  // namespace
+
+extern "C" int64_t adn_frontend_workspace_bytes(int32_t B, int32_t T, int32_t mode) {
+  if (B <= 0 || T <= 0 || mode < 0 || mode > 2) return -1;
+  return fe_dims(B, T, mode).total * 4;
+}
+
+extern "C" int adn_frontend(const float* wave, int32_t B, int32_t T, int32_t mode, int32_t S, int32_t antialias,
+                            float* out, void* workspace, int64_t workspace_bytes, void* stream) {
+  ADN_CHECK_ARG(wave && out && workspace && B > 0 && S > 0, "adn_frontend: bad arguments");
+  ADN_CHECK_ARG(mode >= 0 && mode <= 2, "adn_frontend: bad mode %d", mode);
+  ADN_CHECK_ARG(T > PAD, "adn_frontend: reflect padding needs T > %d samples (got %d)", PAD, T);
+  const FeDims d = fe_dims(B, T, mode);
+  ADN_CHECK_ARG(workspace_bytes >= d.total * 4, "adn_frontend: workspace too small");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  float* ws = reinterpret_cast<float*>(workspace);
+  hipLaunchKernelGGL(fe_tables_kernel, dim3((unsigned)adn_cdiv(NBIN * WIN, 256)), dim3(256), 0, st, ws + d.off_cos,
+                     ws + d.off_sin, ws + d.off_fb);
+  ADN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(fe_stft_kernel, dim3(d.tiles, B * 2), dim3(256), 0, st, wave, T, d.hop, d.nT, mode,
+                     ws + d.off_cos, ws + d.off_sin, ws + d.off_fb, ws + d.off_spec, ws + d.off_mm, d.tiles);
+  ADN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(fe_resize_kernel, dim3((unsigned)adn_cdiv((int64_t)S * S, 256), B * 2), dim3(256), 0, st,
+                     ws + d.off_spec, ws + d.off_mm, d.tiles, d.F, d.nT, S, antialias, mode != 2 ? 1 : 0, out);
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}

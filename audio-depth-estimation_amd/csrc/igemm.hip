@@ -1,0 +1,566 @@
+// Implicit-GEMM convolution family for k4/s2/p1 Conv2d and ConvTranspose2d (gfx950).
+//
+//   S2:  out[m][n]        = sum_{tap=(ky,kx), c} in[b, 2oy-1+ky, 2ox-1+kx, c] * w[n][tap][c]     m on the small grid
+//   T2:  out[phase, m][n] = sum_{t=(ty,tx), c}  in[b, i+DY(ph,ty), j+DY(pw,tx), c] * w[phase][n][t][c]
+//        written to the large-grid pixel (2i+ph, 2j+pw)
+//
+// MFMA path: 128 x BN output tile per 256-thread workgroup (4 waves as 2x2, each 64 x BN/2),
+// K-step = 128 bytes of channels of one tap (64 bf16 / 32 f32); operands staged through LDS with
+// an XOR swizzle (16-byte chunk ^= (row>>1)&7) so that the ds_read_b128 fragment reads and the
+// ds_write_b128 staging writes are bank-conflict free; register-staged double buffering (global
+// loads of step s+1 are in flight while step s runs on the matrix cores).  Small-M layers use
+// split-K into f32 slabs + a reduce pass.  The epilogue goes through LDS so that every global
+// access of the epilogue is a 16-byte, row-contiguous access.
+#include <stdarg.h>
+
+#include "epilogue.h"
+
+namespace {
+
+struct KParams {
+  const void* in0;
+  const void* in1;
+  const void* w;
+  int B, Hs, Ws, C0, C1, N;
+  int Msmall;     // B*Hs*Ws
+  int kpt;        // K-steps per tap
+  int ksteps;     // total K-steps
+  int nsplit;     // split-K factor (grid.z)
+  int tiles_m, tiles_n;
+  int epi;
+  AdnEpiSeg seg[2];
+  float* slab;    // split-K / generic scratch
+};
+
+constexpr int BM = 128;
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  // bijective XCD-contiguous remap (cdna_hip_programming.md T1): blocks b and b+8 share an XCD.
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+template <typename T>
+__device__ __forceinline__ void mma_tile(const u32x4_t& a, const u32x4_t& b, f32x4_t& acc) {
+  if constexpr (sizeof(T) == 2) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(&a),
+                                                  *reinterpret_cast<const bf16x8_t*>(&b), acc, 0, 0, 0);
+  } else {
+    // exact f32: lane group q=(lane>>4) holds k = 4q..4q+3 of this 16-wide slice for A and B alike;
+    // MFMA step s contracts element s of every lane group (a permutation of k, same on both sides).
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[s]), __uint_as_float(b[s]), acc, 0, 0, 0);
+  }
+}
+
+template <typename T, int BN, int GEOM>
+__global__ __launch_bounds__(256, 2) void igemm_mfma_kernel(KParams p) {
+  constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
+  constexpr int BK = 8 * EPC;               // elements per K-step (128 bytes)
+  constexpr int WN = BN / 2;                // wave tile columns
+  constexpr int NT = WN / 16;
+  constexpr int MT = 4;
+  constexpr int BROWS = BN / 32;            // B rows per thread
+  constexpr int LDC = BN + 4;               // epilogue tile leading dimension (floats)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* As = smem;                       // [2][BM][128 B]
+  char* Bs = smem + 2 * BM * 128;        // [2][BN][128 B]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int wg = xcd_remap(blockIdx.x, nwg);
+  const int tile_n = wg % p.tiles_n;
+  const int tile_m = wg / p.tiles_n;
+  const int phase = blockIdx.y;
+  const int ph = phase >> 1, pw = phase & 1;
+  const int split = blockIdx.z;
+
+  const int Hs = p.Hs, Ws = p.Ws;
+  const int Hl = 2 * Hs, Wl = 2 * Ws;
+  const int Cin = p.C0 + p.C1;
+
+  // ---- loader geometry ----
+  const int chunk = tid & 7;
+  const int lrow = tid >> 3;  // 0..31
+  int a_b[4], a_y[4], a_x[4];
+  bool a_ok[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = tile_m * BM + lrow + 32 * j;
+    a_ok[j] = m < p.Msmall;
+    const int mm = a_ok[j] ? m : 0;
+    const int b = mm / (Hs * Ws);
+    const int rem = mm - b * (Hs * Ws);
+    const int i = rem / Ws;
+    a_b[j] = b;
+    a_y[j] = i;
+    a_x[j] = rem - i * Ws;
+  }
+
+  const int s_begin = (int)(((int64_t)p.ksteps * split) / p.nsplit);
+  const int s_end = (int)(((int64_t)p.ksteps * (split + 1)) / p.nsplit);
+
+  u32x4_t ra[4], rb[BROWS];
+
+  auto load_step = [&](int s) {
+    const int tap = s / p.kpt;
+    const int c0 = (s - tap * p.kpt) * BK;
+    const T* src;
+    int Csrc, coff;
+    if (c0 < p.C0) {
+      src = reinterpret_cast<const T*>(p.in0);
+      Csrc = p.C0;
+      coff = c0;
+    } else {
+      src = reinterpret_cast<const T*>(p.in1);
+      Csrc = p.C1;
+      coff = c0 - p.C0;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int iy, ix, H, W;
+      if constexpr (GEOM == ADN_GEMM_S2) {
+        iy = 2 * a_y[j] - 1 + (tap >> 2);
+        ix = 2 * a_x[j] - 1 + (tap & 3);
+        H = Hl;
+        W = Wl;
+      } else {
+        iy = a_y[j] + adn_t2_dy(ph, tap >> 1);
+        ix = a_x[j] + adn_t2_dy(pw, tap & 1);
+        H = Hs;
+        W = Ws;
+      }
+      const bool ok = a_ok[j] && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      u32x4_t v = {0u, 0u, 0u, 0u};
+      if (ok) {
+        const int64_t pix = ((int64_t)a_b[j] * H + iy) * W + ix;
+        v = *reinterpret_cast<const u32x4_t*>(src + pix * Csrc + coff + chunk * EPC);
+      }
+      ra[j] = v;
+    }
+    const T* w = reinterpret_cast<const T*>(p.w);
+#pragma unroll
+    for (int j = 0; j < BROWS; ++j) {
+      const int n = tile_n * BN + lrow + 32 * j;
+      int64_t off;
+      if constexpr (GEOM == ADN_GEMM_S2)
+        off = ((int64_t)n * 16 + tap) * Cin + c0 + chunk * EPC;
+      else
+        off = (((int64_t)phase * p.N + n) * 4 + tap) * Cin + c0 + chunk * EPC;
+      rb[j] = *reinterpret_cast<const u32x4_t*>(w + off);
+    }
+  };
+  auto store_step = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = lrow + 32 * j;
+      *reinterpret_cast<u32x4_t*>(As + buf * (BM * 128) + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)) = ra[j];
+    }
+#pragma unroll
+    for (int j = 0; j < BROWS; ++j) {
+      const int row = lrow + 32 * j;
+      *reinterpret_cast<u32x4_t*>(Bs + buf * (BN * 128) + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)) = rb[j];
+    }
+  };
+
+  f32x4_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  if (s_begin < s_end) {
+    load_step(s_begin);
+    store_step(0);
+  }
+  __syncthreads();
+
+  const int frow = lane & 15;
+  const int fq = lane >> 4;
+  for (int s = s_begin; s < s_end; ++s) {
+    const int cur = (s - s_begin) & 1;
+    const bool more = (s + 1) < s_end;
+    if (more) load_step(s + 1);
+    const char* Ab = As + cur * (BM * 128);
+    const char* Bb = Bs + cur * (BN * 128);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      u32x4_t af[MT], bf[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int row = wm * 64 + i * 16 + frow;
+        af[i] = *reinterpret_cast<const u32x4_t*>(Ab + row * 128 + (((ks * 4 + fq) ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int row = wn * WN + j * 16 + frow;
+        bf[j] = *reinterpret_cast<const u32x4_t*>(Bb + row * 128 + (((ks * 4 + fq) ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) mma_tile<T>(af[i], bf[j], acc[i][j]);
+    }
+    if (more) store_step(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue through LDS: ctile[BM][LDC] f32 ----
+  float* ct = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        ct[(wm * 64 + i * 16 + 4 * fq + r) * LDC + wn * WN + j * 16 + frow] = acc[i][j][r];
+  __syncthreads();
+
+  constexpr int CPR = BN / 8;        // 8-channel column groups per row
+  constexpr int RSTEP = 256 / CPR;   // rows covered per pass
+  constexpr int RPT = BM / RSTEP;    // rows per thread
+  const int cg = tid % CPR;
+  const int rsub = tid / CPR;
+  const int n0 = tile_n * BN + cg * 8;
+
+  int epi = p.epi;
+  AdnEpiSeg sg;
+  int nl;
+  int64_t mout_total = (GEOM == ADN_GEMM_S2) ? (int64_t)p.Msmall : (int64_t)p.Msmall * 4;
+  if (p.nsplit > 1) {
+    epi = ADN_EPI_RAW;
+    sg = p.seg[0];
+    sg.out0 = p.slab + (int64_t)split * mout_total * p.N;
+    sg.channels = p.N;
+    sg.partials = nullptr;
+    nl = n0;
+  } else if (n0 < p.seg[0].channels) {
+    sg = p.seg[0];
+    nl = n0;
+  } else {
+    sg = p.seg[1];
+    nl = n0 - p.seg[0].channels;
+  }
+  EpiCols cols;
+  epi_cols_init<T>(epi, sg, nl, cols);
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    const int row = rsub + RSTEP * k;
+    const int m = tile_m * BM + row;
+    if (m < p.Msmall) {
+      int64_t op;
+      if constexpr (GEOM == ADN_GEMM_S2) {
+        op = m;
+      } else {
+        const int b = m / (Hs * Ws);
+        const int rem = m - b * (Hs * Ws);
+        const int i = rem / Ws;
+        const int jx = rem - i * Ws;
+        op = ((int64_t)b * Hl + 2 * i + ph) * Wl + 2 * jx + pw;
+      }
+      float v[8];
+      const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(ct + row * LDC + cg * 8);
+      const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(ct + row * LDC + cg * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = v0[e];
+        v[4 + e] = v1[e];
+      }
+      epi_vec8<T>(epi, sg, cols, op, nl, v, s1, s2);
+    }
+  }
+
+  if (sg.partials != nullptr && (epi == ADN_EPI_Z_STATS || epi == ADN_EPI_BWD)) {
+    // reduce over the row subsets: lanes sharing cg inside a wave, then the 4 waves through LDS.
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int o = CPR; o < 64; o <<= 1) {
+        s1[e] += __shfl_xor(s1[e], o, 64);
+        s2[e] += __shfl_xor(s2[e], o, 64);
+      }
+    }
+    __syncthreads();  // everyone is done reading ctile
+    float* red = reinterpret_cast<float*>(smem);  // [4 waves][2][BN]
+    if (lane < CPR) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[(wave * 2 + 0) * BN + cg * 8 + e] = s1[e];
+        red[(wave * 2 + 1) * BN + cg * 8 + e] = s2[e];
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int st = tid / BN, c = tid % BN;
+      const float t = red[(0 * 2 + st) * BN + c] + red[(1 * 2 + st) * BN + c] + red[(2 * 2 + st) * BN + c] +
+                      red[(3 * 2 + st) * BN + c];
+      const int n = tile_n * BN + c;
+      const AdnEpiSeg& sq = (n < p.seg[0].channels) ? p.seg[0] : p.seg[1];
+      const int ncl = (n < p.seg[0].channels) ? n : n - p.seg[0].channels;
+      const int64_t P = (int64_t)phase * p.tiles_m + tile_m;
+      if (sq.partials) sq.partials[(P * 2 + st) * sq.channels + ncl] = t;
+    }
+  }
+}
+
+// ---- generic direct path: any channel counts, one thread per output element, f32 slab out ----
+template <typename T, int GEOM>
+__global__ __launch_bounds__(256) void igemm_direct_kernel(KParams p) {
+  const int Hs = p.Hs, Ws = p.Ws, Hl = 2 * Hs, Wl = 2 * Ws;
+  const int Cin = p.C0 + p.C1;
+  const int64_t mout = (GEOM == ADN_GEMM_S2) ? (int64_t)p.Msmall : (int64_t)p.Msmall * 4;
+  const int64_t total = mout * p.N;
+  const T* in0 = reinterpret_cast<const T*>(p.in0);
+  const T* in1 = reinterpret_cast<const T*>(p.in1);
+  const T* w = reinterpret_cast<const T*>(p.w);
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t op = e / p.N;
+    const int n = (int)(e - op * p.N);
+    float acc = 0.f;
+    if constexpr (GEOM == ADN_GEMM_S2) {
+      const int b = (int)(op / (Hs * Ws));
+      const int rem = (int)(op - (int64_t)b * (Hs * Ws));
+      const int oy = rem / Ws, ox = rem - oy * Ws;
+      for (int tap = 0; tap < 16; ++tap) {
+        const int iy = 2 * oy - 1 + (tap >> 2), ix = 2 * ox - 1 + (tap & 3);
+        if ((unsigned)iy >= (unsigned)Hl || (unsigned)ix >= (unsigned)Wl) continue;
+        const int64_t pix = ((int64_t)b * Hl + iy) * Wl + ix;
+        const T* wr = w + ((int64_t)n * 16 + tap) * Cin;
+        for (int c = 0; c < p.C0; ++c) acc += ElemTraits<T>::load(in0 + pix * p.C0 + c) * ElemTraits<T>::load(wr + c);
+        for (int c = 0; c < p.C1; ++c)
+          acc += ElemTraits<T>::load(in1 + pix * p.C1 + c) * ElemTraits<T>::load(wr + p.C0 + c);
+      }
+    } else {
+      const int b = (int)(op / ((int64_t)Hl * Wl));
+      const int rem = (int)(op - (int64_t)b * Hl * Wl);
+      const int oy = rem / Wl, ox = rem - oy * Wl;
+      const int ph = oy & 1, pw = ox & 1, i = oy >> 1, jx = ox >> 1;
+      const int phase = ph * 2 + pw;
+      for (int t = 0; t < 4; ++t) {
+        const int iy = i + adn_t2_dy(ph, t >> 1), ix = jx + adn_t2_dy(pw, t & 1);
+        if ((unsigned)iy >= (unsigned)Hs || (unsigned)ix >= (unsigned)Ws) continue;
+        const int64_t pix = ((int64_t)b * Hs + iy) * Ws + ix;
+        const T* wr = w + (((int64_t)phase * p.N + n) * 4 + t) * Cin;
+        for (int c = 0; c < p.C0; ++c) acc += ElemTraits<T>::load(in0 + pix * p.C0 + c) * ElemTraits<T>::load(wr + c);
+        for (int c = 0; c < p.C1; ++c)
+          acc += ElemTraits<T>::load(in1 + pix * p.C1 + c) * ElemTraits<T>::load(wr + p.C0 + c);
+      }
+    }
+    p.slab[e] = acc;
+  }
+}
+
+// ---- slab reduce + epilogue: v = sum_s slab[s][op*N+n] ----
+// Column mapping: thread = channel, block = RB consecutive output pixels; the per-channel stats of a
+// block need no cross-thread reduction and the partial row index is the block index.
+constexpr int RB = 64;
+template <typename T>
+__global__ __launch_bounds__(256) void igemm_reduce_kernel(KParams p, int64_t mout) {
+  const int64_t row0 = (int64_t)blockIdx.x * RB;
+  const int64_t slab_stride = mout * p.N;
+  for (int n = threadIdx.x; n < p.N; n += 256) {
+    const bool in0 = n < p.seg[0].channels;
+    const AdnEpiSeg& sg = in0 ? p.seg[0] : p.seg[1];
+    const int nl = in0 ? n : n - p.seg[0].channels;
+    float s1 = 0.f, s2 = 0.f;
+    for (int r = 0; r < RB; ++r) {
+      const int64_t op = row0 + r;
+      if (op >= mout) break;
+      float v = 0.f;
+      for (int s = 0; s < p.nsplit; ++s) v += p.slab[s * slab_stride + op * p.N + n];
+      epi_scalar<T>(p.epi, sg, op, nl, v, s1, s2);
+    }
+    if (sg.partials && (p.epi == ADN_EPI_Z_STATS || p.epi == ADN_EPI_BWD)) {
+      sg.partials[((int64_t)blockIdx.x * 2 + 0) * sg.channels + nl] = s1;
+      sg.partials[((int64_t)blockIdx.x * 2 + 1) * sg.channels + nl] = s2;
+    }
+  }
+}
+
+struct Plan {
+  bool mfma;
+  int bn;
+  int nsplit;
+  int tiles_m, tiles_n, phases;
+  int kpt, ksteps;
+  int64_t mout;
+  int64_t partial_rows;
+  int64_t slab_bytes;
+};
+
+bool make_plan(const AdnIgemmDesc* d, Plan* pl) {
+  const int esz = d->dtype == ADN_BF16 ? 2 : 4;
+  const int bk = 128 / esz;
+  const int Cin = d->C0 + d->C1;
+  const int64_t msmall = (int64_t)d->B * d->Hs * d->Ws;
+  pl->phases = d->geom == ADN_GEMM_T2 ? 4 : 1;
+  pl->mout = msmall * pl->phases;
+  const int taps = d->geom == ADN_GEMM_S2 ? 16 : 4;
+  const bool aligned = (d->C0 % bk == 0) && (d->C1 % bk == 0) && (d->N % 64 == 0) &&
+                       (d->seg[0].channels % 64 == 0) && (d->seg[1].channels % 64 == 0);
+  pl->mfma = aligned;
+  if (!aligned) {
+    pl->bn = 0;
+    pl->nsplit = 1;
+    pl->tiles_m = pl->tiles_n = 0;
+    pl->kpt = pl->ksteps = 0;
+    pl->partial_rows = adn_cdiv(pl->mout, RB);
+    pl->slab_bytes = pl->mout * d->N * 4;
+    return true;
+  }
+  pl->bn = (d->N % 128 == 0 && d->seg[0].channels % 128 == 0) ? 128 : 64;
+  pl->tiles_m = (int)adn_cdiv(msmall, BM);
+  pl->tiles_n = d->N / pl->bn;
+  pl->kpt = Cin / bk;
+  pl->ksteps = taps * pl->kpt;
+  const int64_t tiles = (int64_t)pl->tiles_m * pl->tiles_n * pl->phases;
+  int ns = 1;
+  if (tiles < 256) {
+    ns = (int)adn_cdiv(512, tiles);
+    const int max_by_k = pl->ksteps / 2 > 0 ? pl->ksteps / 2 : 1;
+    if (ns > max_by_k) ns = max_by_k;
+    if (ns > 64) ns = 64;
+    if (ns < 1) ns = 1;
+  }
+  pl->nsplit = ns;
+  if (ns > 1) {
+    pl->partial_rows = adn_cdiv(pl->mout, RB);
+    pl->slab_bytes = (int64_t)ns * pl->mout * d->N * 4;
+  } else {
+    pl->partial_rows = (int64_t)pl->tiles_m * pl->phases;
+    pl->slab_bytes = 0;
+  }
+  return true;
+}
+
+template <typename T, int BN, int GEOM>
+int launch_mfma(const KParams& kp, const Plan& pl, hipStream_t st) {
+  const int stage = 2 * (BM + BN) * 128;
+  const int epil = BM * (BN + 4) * 4;
+  const int lds = stage > epil ? stage : epil;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_mfma_kernel<T, BN, GEOM>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  dim3 grid(pl.tiles_m * pl.tiles_n, pl.phases, pl.nsplit);
+  hipLaunchKernelGGL((igemm_mfma_kernel<T, BN, GEOM>), grid, dim3(256), lds, st, kp);
+  return 0;
+}
+
+template <typename T>
+int run(const AdnIgemmDesc* d, const Plan& pl, hipStream_t st) {
+  KParams kp;
+  kp.in0 = d->in0;
+  kp.in1 = d->in1;
+  kp.w = d->w;
+  kp.B = d->B;
+  kp.Hs = d->Hs;
+  kp.Ws = d->Ws;
+  kp.C0 = d->C0;
+  kp.C1 = d->C1;
+  kp.N = d->N;
+  kp.Msmall = d->B * d->Hs * d->Ws;
+  kp.kpt = pl.kpt;
+  kp.ksteps = pl.ksteps;
+  kp.nsplit = pl.nsplit;
+  kp.tiles_m = pl.tiles_m;
+  kp.tiles_n = pl.tiles_n;
+  kp.epi = d->epi;
+  kp.seg[0] = d->seg[0];
+  kp.seg[1] = d->seg[1];
+  kp.slab = reinterpret_cast<float*>(d->workspace);
+  if (pl.mfma) {
+    if (d->geom == ADN_GEMM_S2) {
+      if (pl.bn == 128) launch_mfma<T, 128, ADN_GEMM_S2>(kp, pl, st);
+      else launch_mfma<T, 64, ADN_GEMM_S2>(kp, pl, st);
+    } else {
+      if (pl.bn == 128) launch_mfma<T, 128, ADN_GEMM_T2>(kp, pl, st);
+      else launch_mfma<T, 64, ADN_GEMM_T2>(kp, pl, st);
+    }
+    ADN_CHECK_LAUNCH();
+    if (pl.nsplit > 1) {
+      hipLaunchKernelGGL((igemm_reduce_kernel<T>), dim3((unsigned)adn_cdiv(pl.mout, RB)), dim3(256), 0, st, kp,
+                         pl.mout);
+      ADN_CHECK_LAUNCH();
+    }
+  } else {
+    const int64_t total = pl.mout * d->N;
+    int64_t blocks = adn_cdiv(total, 256);
+    if (blocks > 65536) blocks = 65536;
+    if (d->geom == ADN_GEMM_S2)
+      hipLaunchKernelGGL((igemm_direct_kernel<T, ADN_GEMM_S2>), dim3((unsigned)blocks), dim3(256), 0, st, kp);
+    else
+      hipLaunchKernelGGL((igemm_direct_kernel<T, ADN_GEMM_T2>), dim3((unsigned)blocks), dim3(256), 0, st, kp);
+    ADN_CHECK_LAUNCH();
+    kp.nsplit = 1;
+    hipLaunchKernelGGL((igemm_reduce_kernel<T>), dim3((unsigned)adn_cdiv(pl.mout, RB)), dim3(256), 0, st, kp,
+                       pl.mout);
+    ADN_CHECK_LAUNCH();
+  }
+  return ADN_OK;
+}
+
+int validate(const AdnIgemmDesc* d) {
+  ADN_CHECK_ARG(d != nullptr, "adn_igemm: null descriptor");
+  ADN_CHECK_ARG(d->dtype == ADN_F32 || d->dtype == ADN_BF16, "adn_igemm: bad dtype %d", d->dtype);
+  ADN_CHECK_ARG(d->geom == ADN_GEMM_S2 || d->geom == ADN_GEMM_T2, "adn_igemm: bad geom %d", d->geom);
+  ADN_CHECK_ARG(d->B > 0 && d->Hs > 0 && d->Ws > 0, "adn_igemm: bad shape B=%d Hs=%d Ws=%d", d->B, d->Hs, d->Ws);
+  ADN_CHECK_ARG(d->C0 > 0 && d->C1 >= 0 && d->N > 0, "adn_igemm: bad channels C0=%d C1=%d N=%d", d->C0, d->C1, d->N);
+  ADN_CHECK_ARG(d->in0 && d->w && (d->C1 == 0 || d->in1), "adn_igemm: null operand");
+  ADN_CHECK_ARG(d->epi >= ADN_EPI_RAW && d->epi <= ADN_EPI_FINAL, "adn_igemm: bad epilogue %d", d->epi);
+  ADN_CHECK_ARG(d->seg[0].channels + d->seg[1].channels == d->N && d->seg[0].channels > 0 && d->seg[1].channels >= 0,
+                "adn_igemm: segment channels %d+%d != N=%d", d->seg[0].channels, d->seg[1].channels, d->N);
+  for (int s = 0; s < 2; ++s) {
+    if (d->seg[s].channels == 0) continue;
+    const AdnEpiSeg& g = d->seg[s];
+    if (d->epi != ADN_EPI_ACT) ADN_CHECK_ARG(g.out0, "adn_igemm: seg %d out0 is null", s);
+    if (d->epi == ADN_EPI_ACT) ADN_CHECK_ARG(g.out0 || g.out1, "adn_igemm: seg %d has no output", s);
+    if (d->epi == ADN_EPI_BWD) {
+      ADN_CHECK_ARG(g.ref, "adn_igemm: seg %d BWD needs ref", s);
+      if (g.partials) ADN_CHECK_ARG(g.z && g.mean && g.istd, "adn_igemm: seg %d BWD stats need z/mean/istd", s);
+    }
+  }
+  // 32-bit index safety of the per-tensor element counts
+  const int64_t big = (int64_t)d->B * d->Hs * d->Ws * 4;
+  ADN_CHECK_ARG(big * (d->C0 + d->C1) < (1ll << 40) && big < (1ll << 31), "adn_igemm: tensor too large");
+  return ADN_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t adn_igemm_num_partials(const AdnIgemmDesc* d) {
+  if (validate(d) != ADN_OK) return -1;
+  Plan pl;
+  make_plan(d, &pl);
+  return pl.partial_rows;
+}
+
+extern "C" int64_t adn_igemm_workspace_bytes(const AdnIgemmDesc* d) {
+  if (validate(d) != ADN_OK) return -1;
+  Plan pl;
+  make_plan(d, &pl);
+  return pl.slab_bytes;
+}
+
+extern "C" int adn_igemm(const AdnIgemmDesc* d, void* stream) {
+  int rc = validate(d);
+  if (rc != ADN_OK) return rc;
+  Plan pl;
+  make_plan(d, &pl);
+  ADN_CHECK_ARG(pl.slab_bytes == 0 || (d->workspace && d->workspace_bytes >= pl.slab_bytes),
+                "adn_igemm: workspace too small (%lld < %lld)", (long long)d->workspace_bytes,
+                (long long)pl.slab_bytes);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (d->dtype == ADN_BF16) return run<uint16_t>(d, pl, st);
+  return run<float>(d, pl, st);
+}

@@ -1,0 +1,340 @@
+// Masked depth loss, final-activation backward, gradient-norm clip and fused optimizer step.
+// All streaming / reduction kernels (HBM-bound); reductions are two-stage and deterministic:
+// per-block partials in f64, then one block sums them in a fixed order.  No host round trips: the
+// loss statistics, clip coefficient and Adam bias corrections live in device memory so a whole
+// training step can be captured into one hipGraph.
+#include "epilogue.h"
+
+namespace {
+
+constexpr int kRedBlocks = 1024;
+
+__device__ __forceinline__ double block_sum_d(double v, double* sh) {
+  v = wave_sum_d(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[w];
+  return t;
+}
+
+__device__ __forceinline__ bool valid_px(float g, int mask_mode) { return mask_mode == 0 ? (g != 0.0f) : (g > 0.0f); }
+
+__global__ __launch_bounds__(256) void loss_stats_partial_kernel(const float* pred, const float* gt, int64_t n,
+                                                                 float scale, int mask_mode, float eps,
+                                                                 double* partials) {
+  __shared__ double sh[4];
+  double cN = 0.0, sA = 0.0, sD = 0.0, sD2 = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float g0 = gt[i];
+    if (valid_px(g0, mask_mode)) {
+      const float p = pred[i] * scale, g = g0 * scale;
+      const float d = logf(fmaxf(p, eps)) - logf(fmaxf(g, eps));
+      cN += 1.0;
+      sA += (double)fabsf(p - g);
+      sD += (double)d;
+      sD2 += (double)d * (double)d;
+    }
+  }
+  cN = block_sum_d(cN, sh);
+  sA = block_sum_d(sA, sh);
+  sD = block_sum_d(sD, sh);
+  sD2 = block_sum_d(sD2, sh);
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x * 4 + 0] = cN;
+    partials[blockIdx.x * 4 + 1] = sA;
+    partials[blockIdx.x * 4 + 2] = sD;
+    partials[blockIdx.x * 4 + 3] = sD2;
+  }
+}
+
+__global__ __launch_bounds__(256) void sum_partials_kernel(const double* partials, int nblocks, int width,
+                                                           double* out) {
+  __shared__ double sh[4];
+  for (int k = 0; k < width; ++k) {
+    double v = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) v += partials[i * width + k];
+    v = block_sum_d(v, sh);
+    if (threadIdx.x == 0) out[k] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void loss_finish_kernel(const float* pred, const float* gt, int64_t n, float scale,
+                                                          int mask_mode, float eps, const double* stats,
+                                                          int criterion, float l1w, float sw, float lam,
+                                                          float* loss_out, float* grad) {
+  const double N = stats[0];
+  double w1 = criterion == 0 ? 1.0 : (criterion == 1 ? 0.0 : (double)l1w);
+  double w2 = criterion == 0 ? 0.0 : (criterion == 1 ? 1.0 : (double)sw);
+  double l1 = 0.0, silog = 0.0, mean_d = 0.0;
+  if (N > 0.0) {
+    l1 = stats[1] / N;
+    mean_d = stats[2] / N;
+    const double var = stats[3] / N - (double)lam * mean_d * mean_d;
+    silog = var > 0.0 ? sqrt(var) : 0.0;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && loss_out) {
+    // an empty mask gives mean-of-empty = NaN in the reference (train.py:656); keep that signal
+    loss_out[0] = N > 0.0 ? (float)(w1 * l1 + w2 * silog) : __int_as_float(0x7fc00000);
+  }
+  if (!grad) return;
+  const float c1 = N > 0.0 ? (float)(w1 * (double)scale / N) : 0.f;
+  const float c2 = (N > 0.0 && silog > 0.0) ? (float)(w2 * (double)scale / (N * silog)) : 0.f;
+  const float lm = (float)((double)lam * mean_d);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float g0 = gt[i];
+    float gr = 0.f;
+    if (valid_px(g0, mask_mode)) {
+      const float p = pred[i] * scale, g = g0 * scale;
+      const float diff = p - g;
+      gr = c1 * (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f));
+      if (c2 != 0.f && p >= eps) {
+        const float d = logf(p) - logf(fmaxf(g, eps));
+        gr += c2 * (d - lm) / p;
+      }
+    }
+    grad[i] = gr;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void final_act_bwd_kernel(const float* gout, const float* out, int64_t n, int kind,
+                                                            T* dz) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float o = out[i];
+    const float d = kind == 1 ? o * (1.0f - o) : (o > 0.f ? 1.0f : 0.0f);
+    ElemTraits<T>::store(dz + i, gout[i] * d);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sum_partial_kernel(const T* x, int64_t n, double* partials) {
+  __shared__ double sh[4];
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    s += (double)ElemTraits<T>::load(x + i);
+  s = block_sum_d(s, sh);
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void sum_final_f32_kernel(const double* partials, int nblocks, float* out) {
+  __shared__ double sh[4];
+  double v = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) v += partials[i];
+  v = block_sum_d(v, sh);
+  if (threadIdx.x == 0) out[0] = (float)v;
+}
+
+__global__ __launch_bounds__(256) void sqsum_partial_kernel(const float* g, int64_t n, double* partials) {
+  __shared__ double sh[4];
+  double s = 0.0;
+  const int64_t n4 = n >> 2;
+  const f32x4_t* g4 = reinterpret_cast<const f32x4_t*>(g);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const f32x4_t v = g4[i];
+    s += (double)(v[0] * v[0] + v[1] * v[1]) + (double)(v[2] * v[2] + v[3] * v[3]);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const float v = g[(n4 << 2) + threadIdx.x];
+    s += (double)v * v;
+  }
+  s = block_sum_d(s, sh);
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void grad_norm_final_kernel(const double* partials, int nblocks, float max_norm,
+                                                              double* state) {
+  __shared__ double sh[4];
+  double v = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) v += partials[i];
+  v = block_sum_d(v, sh);
+  if (threadIdx.x == 0) {
+    const double total = sqrt(v);
+    double coef = (double)max_norm / (total + 1e-6);   // torch clip_grad_norm_: clamp(max_norm/(total+1e-6), max=1)
+    if (coef > 1.0) coef = 1.0;
+    state[3] = total;
+    state[4] = coef;
+  }
+}
+
+__global__ void optimizer_advance_kernel(double* state, double beta1, double beta2) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const double t = state[0] + 1.0;
+    state[0] = t;
+    state[1] = 1.0 - pow(beta1, t);
+    state[2] = 1.0 - pow(beta2, t);
+  }
+}
+
+__device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, int kind, float lr, float b1,
+                                          float b2, float eps, float wd, float step_size, float inv_sqrt_bc2) {
+  if (kind == 0) p *= (1.0f - lr * wd);            // AdamW: decoupled decay
+  else if (wd != 0.0f) g += wd * p;                 // Adam: L2 in the gradient
+  m = m + (g - m) * (1.0f - b1);                    // exp_avg.lerp_(grad, 1-beta1)
+  v = v * b2 + (1.0f - b2) * g * g;
+  const float denom = sqrtf(v) * inv_sqrt_bc2 + eps;
+  p -= step_size * (m / denom);
+}
+
+__global__ __launch_bounds__(256) void optimizer_step_kernel(float* params, const float* grads, float* m, float* v,
+                                                             int64_t n, int kind, float lr, float b1, float b2,
+                                                             float eps, float wd, int use_clip,
+                                                             const double* state) {
+  const float coef = use_clip ? (float)state[4] : 1.0f;
+  const float step_size = (float)((double)lr / state[1]);
+  const float inv_sqrt_bc2 = (float)(1.0 / sqrt(state[2]));
+  const int64_t n4 = n >> 2;
+  f32x4_t* p4 = reinterpret_cast<f32x4_t*>(params);
+  const f32x4_t* g4 = reinterpret_cast<const f32x4_t*>(grads);
+  f32x4_t* m4 = reinterpret_cast<f32x4_t*>(m);
+  f32x4_t* v4 = reinterpret_cast<f32x4_t*>(v);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4_t p = p4[i];
+    const f32x4_t g = g4[i];
+    if (kind == 2) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) p[k] -= lr * (g[k] * coef);
+    } else {
+      f32x4_t mm = m4[i], vv = v4[i];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float pk = p[k], mk = mm[k], vk = vv[k];
+        adam_elem(pk, g[k] * coef, mk, vk, kind, lr, b1, b2, eps, wd, step_size, inv_sqrt_bc2);
+        p[k] = pk;
+        mm[k] = mk;
+        vv[k] = vk;
+      }
+      m4[i] = mm;
+      v4[i] = vv;
+    }
+    p4[i] = p;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = (n4 << 2) + threadIdx.x;
+    if (kind == 2) {
+      params[i] -= lr * (grads[i] * coef);
+    } else {
+      float pk = params[i], mk = m[i], vk = v[i];
+      adam_elem(pk, grads[i] * coef, mk, vk, kind, lr, b1, b2, eps, wd, step_size, inv_sqrt_bc2);
+      params[i] = pk;
+      m[i] = mk;
+      v[i] = vk;
+    }
+  }
+}
+
+inline unsigned red_blocks(int64_t n) {
+  int64_t b = adn_cdiv(n, 256 * 8);
+  if (b > kRedBlocks) b = kRedBlocks;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int64_t adn_loss_workspace_bytes(int64_t n) { return (int64_t)red_blocks(n) * 4 * 8; }
+
+extern "C" int adn_loss_stats(const float* pred, const float* gt, int64_t n, float scale, int32_t mask_mode,
+                              float eps, double* stats, void* workspace, int64_t workspace_bytes, void* stream) {
+  ADN_CHECK_ARG(pred && gt && n > 0 && stats && workspace, "adn_loss_stats: bad arguments");
+  ADN_CHECK_ARG(mask_mode == 0 || mask_mode == 1, "adn_loss_stats: bad mask_mode %d", mask_mode);
+  const unsigned nb = red_blocks(n);
+  ADN_CHECK_ARG(workspace_bytes >= (int64_t)nb * 32, "adn_loss_stats: workspace too small");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  double* part = reinterpret_cast<double*>(workspace);
+  hipLaunchKernelGGL(loss_stats_partial_kernel, dim3(nb), dim3(256), 0, st, pred, gt, n, scale, mask_mode, eps, part);
+  ADN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, part, (int)nb, 4, stats);
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}
+
+extern "C" int adn_loss_finish(const float* pred, const float* gt, int64_t n, float scale, int32_t mask_mode,
+                               float eps, const double* stats, int32_t criterion, float l1_weight, float silog_weight,
+                               float silog_lambda, float* loss_out, float* grad, void* stream) {
+  ADN_CHECK_ARG(pred && gt && n > 0 && stats, "adn_loss_finish: bad arguments");
+  ADN_CHECK_ARG(criterion >= 0 && criterion <= 2, "adn_loss_finish: bad criterion %d", criterion);
+  ADN_CHECK_ARG(loss_out || grad, "adn_loss_finish: nothing to compute");
+  int64_t nb = grad ? adn_cdiv(n, 256) : 1;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(loss_finish_kernel, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pred,
+                     gt, n, scale, mask_mode, eps, stats, criterion, l1_weight, silog_weight, silog_lambda, loss_out,
+                     grad);
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}
+
+extern "C" int adn_final_act_bwd(const float* gout, const float* out, int64_t n, int32_t final_act, int32_t dtype,
+                                 void* dz, void* stream) {
+  ADN_CHECK_ARG(gout && out && dz && n > 0, "adn_final_act_bwd: bad arguments");
+  ADN_CHECK_ARG(dtype == ADN_F32 || dtype == ADN_BF16, "adn_final_act_bwd: bad dtype %d", dtype);
+  int64_t nb = adn_cdiv(n, 256);
+  if (nb > 4096) nb = 4096;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == ADN_BF16)
+    hipLaunchKernelGGL((final_act_bwd_kernel<uint16_t>), dim3((unsigned)nb), dim3(256), 0, st, gout, out, n, final_act,
+                       reinterpret_cast<uint16_t*>(dz));
+  else
+    hipLaunchKernelGGL((final_act_bwd_kernel<float>), dim3((unsigned)nb), dim3(256), 0, st, gout, out, n, final_act,
+                       reinterpret_cast<float*>(dz));
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}
+
+extern "C" int adn_sum_to_scalar(const void* x, int64_t n, int32_t dtype, float* out, void* workspace,
+                                 int64_t workspace_bytes, void* stream) {
+  ADN_CHECK_ARG(x && out && n > 0 && workspace, "adn_sum_to_scalar: bad arguments");
+  ADN_CHECK_ARG(dtype == ADN_F32 || dtype == ADN_BF16, "adn_sum_to_scalar: bad dtype %d", dtype);
+  const unsigned nb = red_blocks(n);
+  ADN_CHECK_ARG(workspace_bytes >= (int64_t)nb * 8, "adn_sum_to_scalar: workspace too small");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  double* part = reinterpret_cast<double*>(workspace);
+  if (dtype == ADN_BF16)
+    hipLaunchKernelGGL((sum_partial_kernel<uint16_t>), dim3(nb), dim3(256), 0, st,
+                       reinterpret_cast<const uint16_t*>(x), n, part);
+  else
+    hipLaunchKernelGGL((sum_partial_kernel<float>), dim3(nb), dim3(256), 0, st, reinterpret_cast<const float*>(x), n,
+                       part);
+  ADN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sum_final_f32_kernel, dim3(1), dim3(256), 0, st, part, (int)nb, out);
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}
+
+extern "C" int64_t adn_grad_norm_workspace_bytes(int64_t n) { return (int64_t)red_blocks(n) * 8; }
+
+extern "C" int adn_grad_norm(const float* grads, int64_t n, float max_norm, double* state, void* workspace,
+                             int64_t workspace_bytes, void* stream) {
+  ADN_CHECK_ARG(grads && n > 0 && state && workspace, "adn_grad_norm: bad arguments");
+  const unsigned nb = red_blocks(n);
+  ADN_CHECK_ARG(workspace_bytes >= (int64_t)nb * 8, "adn_grad_norm: workspace too small");
+  ADN_CHECK_ARG((reinterpret_cast<uintptr_t>(grads) & 15) == 0, "adn_grad_norm: grads must be 16-byte aligned");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  double* part = reinterpret_cast<double*>(workspace);
+  hipLaunchKernelGGL(sqsum_partial_kernel, dim3(nb), dim3(256), 0, st, grads, n, part);
+  ADN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(grad_norm_final_kernel, dim3(1), dim3(256), 0, st, part, (int)nb, max_norm, state);
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}
+
+extern "C" int adn_optimizer_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                  int32_t kind, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                  int32_t use_clip, double* state, void* stream) {
+  ADN_CHECK_ARG(params && grads && n > 0 && state, "adn_optimizer_step: bad arguments");
+  ADN_CHECK_ARG(kind >= 0 && kind <= 2, "adn_optimizer_step: bad kind %d", kind);
+  ADN_CHECK_ARG(kind == 2 || (exp_avg && exp_avg_sq), "adn_optimizer_step: Adam needs moment buffers");
+  ADN_CHECK_ARG(((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(grads) |
+                  reinterpret_cast<uintptr_t>(exp_avg) | reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) == 0,
+                "adn_optimizer_step: buffers must be 16-byte aligned");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(optimizer_advance_kernel, dim3(1), dim3(64), 0, st, state, (double)beta1, (double)beta2);
+  ADN_CHECK_LAUNCH();
+  int64_t nb = adn_cdiv(n, 256 * 4);
+  if (nb > 8192) nb = 8192;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(optimizer_step_kernel, dim3((unsigned)nb), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq,
+                     n, kind, lr, beta1, beta2, eps, weight_decay, use_clip, state);
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}

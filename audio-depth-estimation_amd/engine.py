@@ -1,0 +1,427 @@
+"""Fused U-Net pipeline on libadn kernels: forward, backward, loss, clip, optimizer.
+
+This is the MI355X-side replacement of what PyTorch dispatches for the reference's
+``model(audio)`` / ``loss.backward()`` / ``clip_grad_norm_`` / ``optimizer.step()``
+(/root/reference/train.py:642-691) for ``models.unetbaseline_model.UnetGenerator``.
+
+Data layout in HBM
+  * activations: NHWC, dtype f32 (exact path) or bf16 (throughput path); per down level i the raw conv
+    output ``zd[i]`` (BN levels only) plus the two materialised consumer views ``ad[i]`` =
+    LeakyReLU(BN(z)) (operand of the next down conv) and ``rd[i]`` = ReLU(BN(z)) (skip operand of the
+    same level's transposed conv); per up level ``zu[i]`` and ``ru[i]`` = ReLU(BN(zu)).  The skip
+    concat (unetbaseline_model.py:235) is virtual: the consumer GEMM reads two base pointers.
+  * parameters / gradients / Adam moments: one flat f32 buffer each, parameters() order, conv weights
+    in torch channels_last memory order ([X][4][4][Y]) which IS the S2 GEMM operand layout; the module's
+    nn.Parameters are views into the flat buffer so state_dict()/load_state_dict()/torch.optim keep working.
+  * per step the f32 master weights are cast/packed to the two GEMM operand forms (adn_pack_weights).
+Gradients become final from the END of the flat buffer towards its start (outermost up layer first,
+outermost down layer last), which is the bucket order of the data-parallel all-reduce (ddp.py).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import kernels as K
+from ._lib import EPI_ACT, EPI_BWD, EPI_FINAL, EPI_Z_STATS, GEMM_S2, GEMM_T2
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+LEAKY = 0.2
+
+
+class _Level:
+    """Static + per-shape state of one U-Net level (down conv Li / up convT Di)."""
+    pass
+
+
+def _align(n, a=4):
+    return (n + a - 1) // a * a
+
+
+class UNetEngine:
+    """Runs UnetGenerator.forward/backward through libadn.  One engine per module instance."""
+
+    def __init__(self, module, num_downs, depth_norm, compute_dtype=torch.bfloat16):
+        self.module = module
+        self.n = num_downs
+        self.depth_norm = bool(depth_norm)
+        self.dtype = compute_dtype
+        self.levels = module._adn_levels()          # list of dicts with layer objects, outermost first
+        assert len(self.levels) == num_downs
+        self.flat_p = None
+        self.flat_g = None
+        self.param_meta = []                        # (param, offset, numel)
+        self._shape_key = None
+        self._packed_version = None
+        self.weights_dirty = True
+        self.on_grad_ready = None                   # callback(offset_lo): flat_g[offset_lo:] is final
+        self._saved = None
+
+    # ------------------------------------------------------------------ parameters
+    def _bound(self):
+        if self.flat_p is None:
+            return False
+        p0, off0, _ = self.param_meta[0]
+        pl, offl, _ = self.param_meta[-1]
+        base = self.flat_p.data_ptr()
+        return p0.data_ptr() == base + 4 * off0 and pl.data_ptr() == base + 4 * offl
+
+    def bind_parameters(self):
+        """(Re)create the flat parameter/gradient buffers and re-point the module's Parameters into them."""
+        params = list(self.module.parameters())
+        dev = params[0].device
+        if dev.type != 'cuda':
+            raise RuntimeError('UnetGenerator runs on libadn HIP kernels only: move the model to a HIP device '
+                               '(define_G(..., gpu_ids=[0]) or .to("cuda")); there is no CPU path')
+        total, meta = 0, []
+        for p in params:
+            meta.append((p, total, p.numel()))
+            total += _align(p.numel())
+        flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        for p, off, n in meta:
+            view = self._view(flat_p, off, p)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = None
+        self.flat_p, self.flat_g, self.param_meta, self.total = flat_p, flat_g, meta, total
+        self.offset = {id(p): off for p, off, _ in meta}
+        self.weights_dirty = True
+        self._shape_key = None
+
+    @staticmethod
+    def _view(flat, off, p):
+        n = p.numel()
+        if p.dim() == 4:
+            X, Y, kh, kw = p.shape
+            return flat[off:off + n].view(X, kh, kw, Y).permute(0, 3, 1, 2)
+        return flat[off:off + n].view(p.shape)
+
+    def grad_view(self, p):
+        return self._view(self.flat_g, self.offset[id(p)], p)
+
+    def _flat_slice(self, buf, p):
+        off = self.offset[id(p)]
+        return buf[off:off + p.numel()]
+
+    def _version_sum(self):
+        return sum(p._version for p, _, _ in self.param_meta)
+
+    def _pack_weights(self):
+        T = self.dtype
+        for lv in self.levels:
+            for key in ('down', 'up'):
+                w = lv[key].weight
+                X, Y = w.shape[0], w.shape[1]
+                master = self._flat_slice(self.flat_p, w)
+                if T == torch.float32:
+                    lv[key + '_s2'] = master                       # channels_last memory == S2 operand
+                    K.pack_weights(master, X, Y, T, None, lv[key + '_t2'])
+                else:
+                    K.pack_weights(master, X, Y, T, lv[key + '_s2'], lv[key + '_t2'])
+        self.weights_dirty = False
+        self._packed_version = self._version_sum()
+
+    # ------------------------------------------------------------------ buffers
+    def _prepare(self, x):
+        if not self._bound():
+            self.bind_parameters()
+        B, Cin, H, W = x.shape
+        n = self.n
+        if H % (1 << n) or W % (1 << n):
+            raise RuntimeError(f'input {H}x{W} is not divisible by 2^{n}: Kernel size can\'t be greater than '
+                               f'actual input size')
+        key = (B, Cin, H, W, x.device)
+        if key == self._shape_key:
+            return
+        dev, T = x.device, self.dtype
+        f32 = dict(dtype=torch.float32, device=dev)
+        ws_bytes = 16
+        self.x_nhwc = torch.empty(B, H, W, Cin, dtype=T, device=dev)
+        for i, lv in enumerate(self.levels):
+            dw, uw = lv['down'].weight, lv['up'].weight
+            cd_in, cd_out = dw.shape[1], dw.shape[0]
+            cu_in, cu_out = uw.shape[0], uw.shape[1]
+            hs, wsz = H >> (i + 1), W >> (i + 1)
+            lv.update(hs=hs, ws=wsz, cd_in=cd_in, cd_out=cd_out, cu_in=cu_in, cu_out=cu_out)
+            act = lambda c, h=hs, w_=wsz: torch.empty(B, h, w_, c, dtype=T, device=dev)
+            lv['ad'] = act(cd_out) if i < n - 1 else None
+            lv['rd'] = act(cd_out)
+            lv['Gd'] = act(cd_out)
+            lv['zd'] = act(cd_out) if lv['bn_d'] is not None else None
+            big = lambda c, h=hs, w_=wsz: torch.empty(B, 2 * h, 2 * w_, c, dtype=T, device=dev)
+            if i > 0:
+                lv['zu'] = big(cu_out)
+                lv['ru'] = big(cu_out)
+                lv['Gu'] = big(cu_out)
+            else:
+                lv['out'] = torch.empty(B, 2 * hs, 2 * wsz, cu_out, **f32)
+                lv['dz0'] = big(cu_out)
+            # packed weights
+            if T != torch.float32:
+                lv['down_s2'] = torch.empty(cd_out, 16, cd_in, dtype=T, device=dev)
+                lv['up_s2'] = torch.empty(cu_in, 16, cu_out, dtype=T, device=dev)
+            lv['down_t2'] = torch.empty(4, cd_in, 4, cd_out, dtype=T, device=dev)
+            lv['up_t2'] = torch.empty(4, cu_out, 4, cu_in, dtype=T, device=dev)
+            # GEMM plans: partial rows + workspace
+            c_up0 = cd_out
+            c_up1 = cu_in - cd_out
+            pd, w1 = K.igemm_query(T, GEMM_S2, B, hs, wsz, cd_in, 0, cd_out, [cd_out])            # Li fwd
+            pu, w2 = K.igemm_query(T, GEMM_T2, B, hs, wsz, c_up0, c_up1, cu_out, [cu_out])         # Di fwd
+            pgu, w3 = K.igemm_query(T, GEMM_S2, B, hs, wsz, cu_out, 0, cu_in,                       # Di dgrad
+                                    [c_up0, c_up1] if c_up1 else [c_up0])
+            pgd, w4 = K.igemm_query(T, GEMM_T2, B, hs, wsz, cd_out, 0, cd_in, [cd_in])             # Li dgrad
+            w5 = K.wgrad_workspace_bytes(T, B, hs, wsz, cd_out, 0, cd_in, 0)                       # Li wgrad
+            w6 = K.wgrad_workspace_bytes(T, B, hs, wsz, c_up0, c_up1, cu_out, 0)                   # Di wgrad
+            ws_bytes = max(ws_bytes, w1, w2, w3, w4, w5, w6)
+            lv.update(P_d=pd, P_u=pu, P_gu=pgu, P_gd=pgd)
+            for tag, bn, C in (('d', lv['bn_d'], cd_out), ('u', lv['bn_u'], cu_out)):
+                if bn is None:
+                    continue
+                for nm in ('mean', 'istd', 'scale', 'shift'):
+                    lv[f'{nm}_{tag}'] = torch.empty(C, **f32)
+                lv[f'coef_{tag}'] = torch.empty(2 * C, **f32)
+                lv[f'part_{tag}'] = torch.empty((pd if tag == 'd' else pu) * 2 * C, **f32)
+        # backward stats partials: the tensor BN'd at (level i, tag) receives its final gradient from
+        #   tag 'u' (zu[i], i>=1): dgrad of D(i-1)  -> P_gu of level i-1
+        #   tag 'd' (zd[i], 1<=i<=n-2): dgrad of L(i+1) -> P_gd of level i+1
+        for i, lv in enumerate(self.levels):
+            if lv['bn_u'] is not None:
+                lv['bpart_u'] = torch.empty(self.levels[i - 1]['P_gu'] * 2 * lv['cu_out'], **f32)
+            if lv['bn_d'] is not None:
+                lv['bpart_d'] = torch.empty(self.levels[i + 1]['P_gd'] * 2 * lv['cd_out'], **f32)
+        self.workspace = torch.empty(ws_bytes // 4 + 4, **f32)
+        self.red_ws = torch.empty(4096, dtype=torch.float64, device=dev)
+        self.weights_dirty = True
+        self._shape_key = key
+        self.B = B
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, training):
+        if not x.is_cuda:
+            raise RuntimeError('UnetGenerator.forward needs a HIP device tensor (libadn has no CPU path)')
+        x = x.contiguous().float()
+        self._prepare(x)
+        if self.weights_dirty or self._packed_version != self._version_sum():
+            self._pack_weights()
+        T, B, n, L, ws = self.dtype, self.B, self.n, self.levels, self.workspace
+        K.nchw_to_nhwc(x, self.x_nhwc)
+        # ---- down path
+        for i, lv in enumerate(L):
+            src = self.x_nhwc if i == 0 else L[i - 1]['ad']
+            C, hs, wsz = lv['cd_out'], lv['hs'], lv['ws']
+            bn = lv['bn_d']
+            if bn is None:
+                K.igemm(T, GEMM_S2, B, hs, wsz, src, None, lv['down_s2'], C, EPI_ACT,
+                        [K.Seg(C, out0=lv['ad'], out1=lv['rd'], slope=LEAKY)], ws)
+            elif training:
+                K.igemm(T, GEMM_S2, B, hs, wsz, src, None, lv['down_s2'], C, EPI_Z_STATS,
+                        [K.Seg(C, out0=lv['zd'], partials=lv['part_d'])], ws)
+                self._bn_finalize(lv, 'd', bn, B * hs * wsz, lv['P_d'])
+                K.bn_act(lv['zd'], B * hs * wsz, C, lv['scale_d'], lv['shift_d'], LEAKY, lv['ad'], lv['rd'])
+            else:
+                K.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var, BN_EPS, lv['scale_d'],
+                                 lv['shift_d'])
+                K.igemm(T, GEMM_S2, B, hs, wsz, src, None, lv['down_s2'], C, EPI_ACT,
+                        [K.Seg(C, out0=lv['ad'], out1=lv['rd'], scale=lv['scale_d'], shift=lv['shift_d'],
+                               slope=LEAKY)], ws)
+        # ---- up path
+        for i in reversed(range(n)):
+            lv = L[i]
+            in0 = lv['rd']
+            in1 = L[i + 1]['ru'] if i < n - 1 else None
+            C, hs, wsz = lv['cu_out'], lv['hs'], lv['ws']
+            bn = lv['bn_u']
+            if i == 0:
+                bias = lv['up'].bias
+                K.igemm(T, GEMM_T2, B, hs, wsz, in0, in1, lv['up_t2'], C, EPI_FINAL,
+                        [K.Seg(C, out0=lv['out'], bias=bias, final_act=1 if self.depth_norm else 0)], ws)
+            elif training:
+                K.igemm(T, GEMM_T2, B, hs, wsz, in0, in1, lv['up_t2'], C, EPI_Z_STATS,
+                        [K.Seg(C, out0=lv['zu'], partials=lv['part_u'])], ws)
+                self._bn_finalize(lv, 'u', bn, B * 4 * hs * wsz, lv['P_u'])
+                K.bn_act(lv['zu'], B * 4 * hs * wsz, C, lv['scale_u'], lv['shift_u'], 0.0, None, lv['ru'])
+            else:
+                K.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var, BN_EPS, lv['scale_u'],
+                                 lv['shift_u'])
+                K.igemm(T, GEMM_T2, B, hs, wsz, in0, in1, lv['up_t2'], C, EPI_ACT,
+                        [K.Seg(C, out1=lv['ru'], scale=lv['scale_u'], shift=lv['shift_u'])], ws)
+        out = L[0]['out']                                   # [B, H, W, Cout] f32
+        Cout = L[0]['cu_out']
+        if Cout == 1:
+            return out.view(B, 1, out.shape[1], out.shape[2])
+        res = torch.empty(B, Cout, out.shape[1], out.shape[2], dtype=torch.float32, device=out.device)
+        K.nhwc_to_nchw(out, res)
+        return res
+
+    def _bn_finalize(self, lv, tag, bn, count, P):
+        track = bn.track_running_stats and bn.running_mean is not None
+        K.bn_fwd_finalize(lv[f'part_{tag}'], P, lv[f'mean_{tag}'].numel(), count, bn.weight, bn.bias, BN_EPS,
+                          BN_MOMENTUM if bn.momentum is None else bn.momentum,
+                          bn.running_mean if track else None, bn.running_var if track else None,
+                          bn.num_batches_tracked if track else None,
+                          lv[f'mean_{tag}'], lv[f'istd_{tag}'], lv[f'scale_{tag}'], lv[f'shift_{tag}'])
+
+    # ------------------------------------------------------------------ backward
+    def _ready(self, param):
+        if self.on_grad_ready is not None:
+            self.on_grad_ready(self.offset[id(param)])
+
+    def backward(self, gout):
+        """gout: d loss / d output, f32 [B, Cout, H, W].  Fills flat_g (all parameters)."""
+        T, B, n, L, ws = self.dtype, self.B, self.n, self.levels, self.workspace
+        l0 = L[0]
+        if l0['cu_out'] != 1:
+            raise NotImplementedError('backward is implemented for output_nc == 1 (the depth map)')
+        gout = gout.contiguous().float()
+        K.final_act_bwd(gout, l0['out'], 1 if self.depth_norm else 0, l0['dz0'])
+        up0 = l0['up']
+        if up0.bias is not None:
+            K.sum_to_scalar(l0['dz0'], self._flat_slice(self.flat_g, up0.bias), self.red_ws)
+        # ---- up layers, outermost first
+        for i in range(n):
+            lv = L[i]
+            hs, wsz = lv['hs'], lv['ws']
+            if i == 0:
+                dz = lv['dz0']
+            else:
+                bn = lv['bn_u']
+                C = lv['cu_out']
+                K.bn_bwd_finalize(lv['bpart_u'], L[i - 1]['P_gu'], C, B * 4 * hs * wsz,
+                                  self._flat_slice(self.flat_g, bn.weight), self._flat_slice(self.flat_g, bn.bias),
+                                  lv['coef_u'])
+                K.bn_bwd_apply(lv['Gu'], lv['zu'], B * 4 * hs * wsz, C, lv['scale_u'], lv['mean_u'], lv['istd_u'],
+                               lv['coef_u'])
+                dz = lv['Gu']
+            in0 = lv['rd']
+            in1 = L[i + 1]['ru'] if i < n - 1 else None
+            K.wgrad(T, B, hs, wsz, in0, in1, dz, None, self._flat_slice(self.flat_g, lv['up'].weight), ws)
+            self._ready(lv['up'].weight)
+            segs = [K.Seg(lv['cd_out'], out0=lv['Gd'], ref=lv['rd'], slope=0.0)]
+            if i < n - 1:
+                nx = L[i + 1]
+                segs.append(K.Seg(nx['cu_out'], out0=nx['Gu'], ref=nx['ru'], slope=0.0, z=nx['zu'],
+                                  mean=nx['mean_u'], istd=nx['istd_u'], partials=nx['bpart_u']))
+            K.igemm(T, GEMM_S2, B, hs, wsz, dz, None, lv['up_s2'], lv['cu_in'], EPI_BWD, segs, ws)
+        # ---- down layers, innermost first
+        for i in reversed(range(n)):
+            lv = L[i]
+            hs, wsz = lv['hs'], lv['ws']
+            if lv['bn_d'] is not None:
+                bn, C = lv['bn_d'], lv['cd_out']
+                K.bn_bwd_finalize(lv['bpart_d'], L[i + 1]['P_gd'], C, B * hs * wsz,
+                                  self._flat_slice(self.flat_g, bn.weight), self._flat_slice(self.flat_g, bn.bias),
+                                  lv['coef_d'])
+                K.bn_bwd_apply(lv['Gd'], lv['zd'], B * hs * wsz, C, lv['scale_d'], lv['mean_d'], lv['istd_d'],
+                               lv['coef_d'])
+            src = self.x_nhwc if i == 0 else L[i - 1]['ad']
+            K.wgrad(T, B, hs, wsz, lv['Gd'], None, src, None, self._flat_slice(self.flat_g, lv['down'].weight), ws)
+            self._ready(lv['down'].weight)
+            if i > 0:
+                pv = L[i - 1]
+                seg = K.Seg(pv['cd_out'], out0=pv['Gd'], ref=pv['ad'], slope=LEAKY, accumulate=True)
+                if pv['bn_d'] is not None:
+                    seg = K.Seg(pv['cd_out'], out0=pv['Gd'], ref=pv['ad'], slope=LEAKY, accumulate=True,
+                                z=pv['zd'], mean=pv['mean_d'], istd=pv['istd_d'], partials=pv['bpart_d'])
+                K.igemm(T, GEMM_T2, B, hs, wsz, lv['Gd'], None, lv['down_t2'], lv['cd_in'], EPI_BWD, [seg], ws)
+        if self.on_grad_ready is not None:
+            self.on_grad_ready(0)
+
+
+class _UNetFunction(torch.autograd.Function):
+    """torch.autograd bridge: parameters are inputs so that loss.backward() reaches them."""
+
+    @staticmethod
+    def forward(ctx, x, engine, training, *params):
+        ctx.engine = engine
+        out = engine.forward(x, training)
+        return out.clone()          # engine buffers are reused by the next step
+
+    @staticmethod
+    def backward(ctx, gout):
+        eng = ctx.engine
+        eng.backward(gout)
+        grads = tuple(eng.grad_view(p) for p, _, _ in eng.param_meta)
+        return (None, None, None) + grads
+
+
+def run_unet(engine, x, training):
+    if not engine._bound():
+        engine.bind_parameters()
+    needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p, _, _ in engine.param_meta)
+    if needs_grad and training:
+        return _UNetFunction.apply(x, engine, training, *[p for p, _, _ in engine.param_meta])
+    with torch.no_grad():
+        return engine.forward(x, training).clone()
+
+
+class FusedTrainer:
+    """One fused training step: forward + masked loss + backward + (all-reduce) + clip + optimizer.
+
+    Mirrors the hot loop of /root/reference/train.py:633-693 (and train_binaural_attention.py:394-433 when
+    ``clip_norm`` is None and ``mask_mode`` is 'gt0').  Everything stays on device; ``step`` returns the
+    loss as a 0-dim device tensor (call .item() to reproduce the reference's per-step host sync).
+    """
+    CRIT = {'L1': 0, 'SIlog': 1, 'Combined': 2}
+    OPT = {'AdamW': 0, 'Adam': 1, 'SGD': 2}
+
+    def __init__(self, engine, criterion='Combined', l1_weight=0.5, silog_weight=0.5, silog_lambda=0.5,
+                 max_depth=30.0, optimizer='AdamW', lr=0.002, betas=(0.9, 0.999), eps=1e-8, weight_decay=None,
+                 clip_norm=1.0, mask_mode='ne0', ddp=None):
+        self.engine = engine
+        self.criterion = self.CRIT[criterion]
+        self.l1_weight, self.silog_weight, self.silog_lambda = float(l1_weight), float(silog_weight), float(silog_lambda)
+        self.scale = float(max_depth) if engine.depth_norm else 1.0       # train.py:649-652
+        self.opt_kind = self.OPT[optimizer]
+        self.lr, self.betas, self.eps = float(lr), betas, float(eps)
+        if weight_decay is None:                                           # torch defaults (train.py passes only lr)
+            weight_decay = 0.01 if optimizer == 'AdamW' else 0.0
+        self.weight_decay = float(weight_decay)
+        self.clip_norm = clip_norm
+        self.mask_mode = 0 if mask_mode == 'ne0' else 1
+        self.ddp = ddp
+        self._ready = False
+
+    def _setup(self, dev):
+        eng = self.engine
+        if not eng._bound():
+            eng.bind_parameters()
+        f64 = dict(dtype=torch.float64, device=dev)
+        self.stats = torch.zeros(4, **f64)
+        self.state = torch.zeros(8, **f64)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.loss_ws = torch.empty(4096 + 8, **f64)
+        self.norm_ws = torch.empty(1024 + 8, **f64)
+        self.exp_avg = torch.zeros_like(eng.flat_p)
+        self.exp_avg_sq = torch.zeros_like(eng.flat_p)
+        self.gout = None
+        self._flat_id = eng.flat_p.data_ptr()
+        if self.ddp is not None:
+            self.ddp.attach(eng)
+        self._ready = True
+
+    def step(self, audio, gt):
+        eng = self.engine
+        if not self._ready or self._flat_id != (eng.flat_p.data_ptr() if eng.flat_p is not None else None):
+            self._setup(audio.device)
+        pred = eng.forward(audio, True)
+        gt = gt.contiguous().float()
+        if self.gout is None or self.gout.shape != pred.shape:
+            self.gout = torch.empty_like(pred)
+        K.loss_stats(pred, gt, self.scale, self.mask_mode, 1e-6, self.stats, self.loss_ws)
+        if self.ddp is not None:
+            self.ddp.all_reduce_loss_stats(self.stats)     # one global-batch loss, as under DataParallel
+        K.loss_finish(pred, gt, self.scale, self.mask_mode, 1e-6, self.stats, self.criterion, self.l1_weight,
+                      self.silog_weight, self.silog_lambda, self.loss, self.gout)
+        if self.ddp is not None:
+            self.ddp.begin_backward()
+        eng.backward(self.gout)
+        if self.ddp is not None:
+            self.ddp.finish()
+        if self.clip_norm is not None:
+            K.grad_norm(eng.flat_g, float(self.clip_norm), self.state, self.norm_ws)
+        K.optimizer_step(eng.flat_p, eng.flat_g, self.exp_avg, self.exp_avg_sq, self.opt_kind, self.lr,
+                         self.betas[0], self.betas[1], self.eps, self.weight_decay, self.clip_norm is not None,
+                         self.state)
+        eng.weights_dirty = True
+        return self.loss[0], pred

@@ -1,0 +1,205 @@
+/*
+ * adn.h -- C ABI of libadn.so, the MI355X (gfx950) kernel library behind the
+ * audio-depth-estimation hot path.
+ *
+ * The reference (Kang-ChangWoo/audio-depth-estimation) has no native code and no FFI: its hot
+ * path sits behind Python call signatures.  Each entry point below
+ * therefore cites the *reference Python call site* whose arithmetic it replaces; the Python
+ * mirror in audio-depth-estimation_amd/ keeps those signatures and calls these symbols through
+ * ctypes (see INTEGRATION.md for the binding).
+ *
+ * Conventions
+ *   - plain C symbols, POD arguments, no torch types; every pointer is a DEVICE pointer owned by
+ *     the caller (PyTorch's allocator); the library never allocates, frees or retains memory.
+ *   - every call only LAUNCHES work on the given hipStream_t (void* here) and returns; no host
+ *     synchronisation, so a caller may capture a sequence of calls into a hipGraph.
+ *   - return value: 0 = ok, negative = error; adn_last_error() gives a thread-local message.
+ *   - activations are NHWC ("pixel-major, channel-contiguous") in dtype ADN_F32 or ADN_BF16;
+ *     accumulation, BatchNorm statistics, loss and optimizer state are always f32 (or f64 for
+ *     final reductions).
+ *   - "packed weights": S2 form [N][16][C] (tap = kh*4+kw), T2 form [4][N][4][C]
+ *     (phase = (oy&1)*2+(ox&1), tap = ty*2+tx); see adn_pack_weights.
+ */
+#ifndef ADN_H_
+#define ADN_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADN_OK 0
+#define ADN_ERR_ARG (-1)
+#define ADN_ERR_LAUNCH (-2)
+#define ADN_ERR_UNSUPPORTED (-3)
+
+enum { ADN_F32 = 0, ADN_BF16 = 1 };
+
+/* gather geometry of an implicit GEMM */
+enum {
+  ADN_GEMM_S2 = 0, /* k4 s2 p1 conv forward / k4 s2 p1 transposed-conv dgrad: out = small grid */
+  ADN_GEMM_T2 = 1  /* k4 s2 p1 transposed-conv forward / conv dgrad: out = large grid, 4 phases */
+};
+
+/* epilogue of an implicit GEMM */
+enum {
+  ADN_EPI_RAW = 0,   /* out0 = v as f32 (debug / building block)                                 */
+  ADN_EPI_Z_STATS,   /* out0 = v (dtype), partial sums of v and v*v per channel (train-mode BN)  */
+  ADN_EPI_ACT,       /* y = v*scale[n]+shift[n] (+bias[n]); out0 = leaky(y,slope) if out0,
+                        out1 = relu(y) if out1   (layers without BN, eval-mode BN)               */
+  ADN_EPI_BWD,       /* g = v * (ref>0 ? 1 : slope) (+ out0 if accumulate); out0 = g;
+                        optional partial sums of g and g*xhat, xhat=(z-mean)*istd                */
+  ADN_EPI_FINAL      /* out0(f32) = final_act(v + bias[n]); final_act: 0 relu, 1 sigmoid         */
+};
+
+/* One channel segment of the output (virtual concat: the output channels [0,N) may be split
+ * in two consecutive segments living in different tensors). */
+typedef struct {
+  void* out0;         /* primary output, [pixels][channels] of this segment                      */
+  void* out1;         /* secondary output (ADN_EPI_ACT relu copy) or NULL                        */
+  const void* ref;    /* ADN_EPI_BWD: activated forward tensor (mask source)                     */
+  const void* z;      /* ADN_EPI_BWD stats: raw forward conv output                              */
+  const float* mean;  /* ADN_EPI_BWD stats                                                       */
+  const float* istd;  /* ADN_EPI_BWD stats                                                       */
+  const float* scale; /* ADN_EPI_ACT: per-channel scale or NULL (=1)                             */
+  const float* shift; /* ADN_EPI_ACT: per-channel shift or NULL (=0)                             */
+  const float* bias;  /* ADN_EPI_ACT / ADN_EPI_FINAL: per-channel bias or NULL                   */
+  float* partials;    /* stats partial sums [P][2][channels] or NULL (no stats)                  */
+  int32_t channels;   /* channels in this segment                                                */
+  float slope;        /* leaky slope (ACT: out0; BWD: mask value where ref<=0)                   */
+  int32_t accumulate; /* ADN_EPI_BWD: add the existing out0                                      */
+  int32_t final_act;  /* ADN_EPI_FINAL                                                           */
+} AdnEpiSeg;
+
+typedef struct {
+  int32_t dtype;      /* ADN_F32 / ADN_BF16: dtype of activations and packed weights             */
+  int32_t geom;       /* ADN_GEMM_S2 / ADN_GEMM_T2                                               */
+  int32_t B;          /* batch                                                                   */
+  int32_t Hs, Ws;     /* SMALL grid (S2: output; T2: input)                                      */
+  int32_t C0, C1;     /* channels of the two gathered input sources (virtual concat), C1 may be 0*/
+  int32_t N;          /* output channels = seg[0].channels + seg[1].channels                     */
+  const void* in0;    /* gathered input source 0, NHWC                                           */
+  const void* in1;    /* gathered input source 1 or NULL                                         */
+  const void* w;      /* packed weights for this geometry                                        */
+  int32_t epi;        /* ADN_EPI_*                                                               */
+  AdnEpiSeg seg[2];
+  void* workspace;    /* split-K / generic-path scratch (f32), adn_igemm_workspace_bytes()       */
+  int64_t workspace_bytes;
+} AdnIgemmDesc;
+
+const char* adn_last_error(void);
+int adn_version(void);
+
+/* Number of stats partial rows P the implicit GEMM will write for this descriptor. */
+int64_t adn_igemm_num_partials(const AdnIgemmDesc* d);
+int64_t adn_igemm_workspace_bytes(const AdnIgemmDesc* d);
+
+/* Implicit-GEMM convolution family.
+ * Replaces: nn.Conv2d(k4,s2,p1) forward  (models/unetbaseline_model.py:187-188)   [S2]
+ *           nn.ConvTranspose2d(k4,s2,p1) forward (:196-198,:209-211,:218-220)      [T2]
+ *           and their input-gradient passes inside loss.backward() (train.py:674). */
+int adn_igemm(const AdnIgemmDesc* d, void* stream);
+
+/* Weight-gradient pass of both layer kinds (train.py:674 loss.backward()).
+ *   dW[r][tap][c] = sum_m plain[m][r] * gather_tap(gath)[m][c]        (f32, [R][16][C])
+ * conv:  plain = dZ (small grid, R = Cout), gath = layer input  (large grid, C = Cin, 2 sources)
+ * convT: plain = layer input (small grid, R = Cin, 2 sources), gath = dZ (large grid, C = Cout) */
+typedef struct {
+  int32_t dtype;
+  int32_t B, Hs, Ws;          /* small grid */
+  const void* plain0; const void* plain1; int32_t R0, R1;
+  const void* gath0;  const void* gath1;  int32_t C0, C1;
+  float* dw;                  /* [R0+R1][16][C0+C1] f32 */
+  void* workspace; int64_t workspace_bytes;
+} AdnWgradDesc;
+int64_t adn_wgrad_workspace_bytes(const AdnWgradDesc* d);
+int adn_wgrad(const AdnWgradDesc* d, void* stream);
+
+/* Cast/pack master f32 weights ([X][4][4][Y] memory order = torch channels_last of an
+ * [X,Y,4,4] parameter) into the two GEMM operand forms.
+ *   s2_out: [X][16][Y] in dtype (plain cast)            or NULL
+ *   t2_out: [4][Y][4][X] in dtype (phase split)         or NULL */
+int adn_pack_weights(const float* master, int32_t X, int32_t Y, int32_t dtype, void* s2_out,
+                     void* t2_out, void* stream);
+
+/* NCHW f32 <-> NHWC dtype layout conversion of the network input/output
+ * (model(audio) boundary, train.py:642). */
+int adn_nchw_to_nhwc(const float* src, void* dst, int32_t B, int32_t C, int32_t H, int32_t W,
+                     int32_t dtype, void* stream);
+int adn_nhwc_to_nchw(const void* src, float* dst, int32_t B, int32_t C, int32_t H, int32_t W,
+                     int32_t dtype, void* stream);
+
+/* BatchNorm2d (nn.BatchNorm2d via get_norm_layer('batch'), unetbaseline_model.py:68-69,190-192).
+ * Train-mode forward finalize: partial sums [P][2][C] -> mean, istd, scale=gamma*istd,
+ * shift=beta-mean*scale; running stats updated with momentum (unbiased variance). */
+int adn_bn_fwd_finalize(const float* partials, int64_t P, int32_t C, int64_t count,
+                        const float* gamma, const float* beta, float eps, float momentum,
+                        float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                        float* mean, float* istd, float* scale, float* shift, void* stream);
+/* Eval-mode: scale/shift from running statistics. */
+int adn_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, int32_t C, float* scale, float* shift,
+                       void* stream);
+/* y = z*scale+shift; out_leaky = leaky(y, slope) (optional), out_relu = relu(y) (optional). */
+int adn_bn_act(const void* z, int64_t pixels, int32_t C, int32_t dtype, const float* scale,
+               const float* shift, float slope, void* out_leaky, void* out_relu, void* stream);
+/* Backward finalize: partial sums of g and g*xhat -> dgamma, dbeta and c1=sum g/count,
+ * c2=sum g*xhat/count (coef[0..C) = c1, coef[C..2C) = c2). */
+int adn_bn_bwd_finalize(const float* partials, int64_t P, int32_t C, int64_t count, float* dgamma,
+                        float* dbeta, float* coef, void* stream);
+/* In place: g <- scale * (g - c1 - xhat*c2), xhat = (z-mean)*istd. */
+int adn_bn_bwd_apply(void* g, const void* z, int64_t pixels, int32_t C, int32_t dtype,
+                     const float* scale, const float* mean, const float* istd, const float* coef,
+                     void* stream);
+
+/* Masked depth loss (train.py:646-669, utils_loss.py:29-49).
+ * stats[0..4) (f64) = N, sum|p-g|, sum d, sum d^2 over valid pixels; mask_mode 0: gt != 0, 1: gt > 0.
+ * adn_loss_stats zeroes nothing: it overwrites stats.  A data-parallel caller all-reduces stats
+ * (4 doubles) between the two calls to reproduce the reference's single global-batch loss. */
+int adn_loss_stats(const float* pred, const float* gt, int64_t n, float scale, int32_t mask_mode,
+                   float eps, double* stats, void* workspace, int64_t workspace_bytes, void* stream);
+int64_t adn_loss_workspace_bytes(int64_t n);
+/* criterion: 0 L1, 1 SIlog, 2 Combined.  loss_out (f32 scalar) and grad (f32, d loss/d pred). */
+int adn_loss_finish(const float* pred, const float* gt, int64_t n, float scale, int32_t mask_mode,
+                    float eps, const double* stats, int32_t criterion, float l1_weight,
+                    float silog_weight, float silog_lambda, float* loss_out, float* grad,
+                    void* stream);
+/* Derivative of the generator's last activation (ReLU or Sigmoid, unetbaseline_model.py:201-206):
+ * dz (dtype, [pixels] single channel NHWC) = gout * act'(out); also dbias partial sums. */
+int adn_final_act_bwd(const float* gout, const float* out, int64_t n, int32_t final_act,
+                      int32_t dtype, void* dz, void* stream);
+/* sum over n f32/dtype elements into one f32 (bias gradient of the outermost ConvTranspose2d). */
+int adn_sum_to_scalar(const void* x, int64_t n, int32_t dtype, float* out, void* workspace,
+                      int64_t workspace_bytes, void* stream);
+
+/* Gradient clipping + optimizer (train.py:689-691: clip_grad_norm_(params, 1.0); optimizer.step()).
+ * state (device, f64[8]): [0] step count, [1] bias_corr1, [2] bias_corr2, [3] total grad norm,
+ * [4] clip coefficient.  All on device: no host round trip, graph-capturable. */
+int adn_grad_norm(const float* grads, int64_t n, float max_norm, double* state, void* workspace,
+                  int64_t workspace_bytes, void* stream);
+int64_t adn_grad_norm_workspace_bytes(int64_t n);
+/* kind: 0 AdamW (decoupled decay), 1 Adam (L2 in gradient), 2 SGD. Advances state[0..2]. */
+int adn_optimizer_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                       int64_t n, int32_t kind, float lr, float beta1, float beta2, float eps,
+                       float weight_decay, int32_t use_clip, double* state, void* stream);
+
+/* Evaluation metrics (compute_errors, utils_criterion.py:6-90), one set of 7 floats per sample:
+ * (abs_rel, rmse, a1, a2, a3, log_10, mae). gt/pred: [samples][pixels] f32. */
+int adn_compute_errors(const float* gt, const float* pred, int32_t samples, int64_t pixels,
+                       float* out7, void* workspace, int64_t workspace_bytes, void* stream);
+int64_t adn_compute_errors_workspace_bytes(int32_t samples, int64_t pixels);
+
+/* Audio front-end (BatvisionV2_Dataset.py:94-135,177-197; BatvisionV1_Dataset.py:68-95;
+ * utils_dataset.py:18-20): wave [B][2][T] f32 -> input [B][2][S][S] f32.
+ * mode 0: BV2 mel (hop 32, 32 mel bins, log, min-max); 1: BV2 linear (hop 16, log, min-max);
+ * 2: BV1 linear (hop 16, raw magnitude).  antialias: torchvision Resize antialias flag. */
+int64_t adn_frontend_workspace_bytes(int32_t B, int32_t T, int32_t mode);
+int adn_frontend(const float* wave, int32_t B, int32_t T, int32_t mode, int32_t S,
+                 int32_t antialias, float* out, void* workspace, int64_t workspace_bytes,
+                 void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADN_H_ */

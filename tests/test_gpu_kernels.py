@@ -1,0 +1,319 @@
+"""GPU parity of the individual libadn kernels against plain torch-CPU fp32 references.
+
+Every call goes through the C ABI (ctypes -> libadn.so).  Tolerances (stated per test):
+  * f32 path (exact-f32 MFMA / f32 VALU): max|err| <= 2e-5 * max|ref|   (accumulation order only)
+  * bf16 path: inputs are pre-rounded to bf16 and the reference is computed in fp32 from the SAME
+    rounded values, so only accumulation order and the final store rounding differ:
+    f32 outputs <= 1e-4 * max|ref|, bf16 outputs <= 6e-3 * max|ref| (one bf16 ulp = 2^-8 relative).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+
+
+def K():
+    from audio_depth_estimation_amd import kernels
+    return kernels
+
+
+def rel_err(a, b):
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def rounded(x, dtype):
+    """Round to the storage dtype and come back to fp32 (what the kernel will actually read)."""
+    return x.to(dtype).float()
+
+
+def nhwc(x, dtype):
+    return x.permute(0, 2, 3, 1).contiguous().to(dtype).to(DEV)
+
+
+def from_nhwc(y):
+    return y.float().cpu().permute(0, 3, 1, 2)
+
+
+def pack(w_xy44, dtype):
+    """[X,Y,4,4] parameter -> (s2 [X,16,Y], t2 [4,Y,4,X]) device tensors through adn_pack_weights."""
+    X, Y = w_xy44.shape[:2]
+    master = w_xy44.permute(0, 2, 3, 1).contiguous().to(DEV)       # channels_last memory order
+    s2 = torch.empty(X, 16, Y, dtype=dtype, device=DEV)
+    t2 = torch.empty(4, Y, 4, X, dtype=dtype, device=DEV)
+    K().pack_weights(master, X, Y, dtype, s2, t2)
+    return s2, t2
+
+
+def ws_for(dtype, geom, B, Hs, Ws, C0, C1, N, segs):
+    P, nbytes = K().igemm_query(dtype, geom, B, Hs, Ws, C0, C1, N, segs)
+    ws = torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=DEV)
+    return P, ws
+
+
+TOL_F32_OUT = {torch.float32: 2e-5, torch.bfloat16: 1e-4}
+TOL_T_OUT = {torch.float32: 2e-5, torch.bfloat16: 6e-3}
+
+# (B, Cin0, Cin1, Cout, Hsmall)   Hsmall = small-grid side
+SHAPES = [
+    (2, 64, 0, 128, 16),     # MFMA, BN=128
+    (2, 64, 64, 64, 8),      # MFMA, BN=64, two gathered sources (virtual concat)
+    (3, 128, 0, 128, 2),     # MFMA, tiny M -> split-K + reduce
+    (8, 64, 0, 128, 64),     # MFMA, >=256 tiles -> fused LDS epilogue (BN=128)
+    (8, 64, 64, 64, 32),     # MFMA, fused epilogue for the 4-phase T2 geometry (BN=64)
+    (2, 6, 0, 10, 4),        # generic direct path
+    (1, 3, 5, 1, 5),         # generic, two sources, single output channel, odd size
+]
+
+
+def test_pack_weights_layout():
+    torch.manual_seed(0)
+    w = torch.randn(6, 10, 4, 4)
+    s2, t2 = pack(w, torch.float32)
+    np.testing.assert_array_equal(s2.cpu().numpy(), w.permute(0, 2, 3, 1).reshape(6, 16, 10).numpy())
+    kh = {(0, 0): 1, (0, 1): 3, (1, 0): 0, (1, 1): 2}
+    t2c = t2.cpu()
+    for ph in range(2):
+        for pw in range(2):
+            for ty in range(2):
+                for tx in range(2):
+                    ref = w[:, :, kh[(ph, ty)], kh[(pw, tx)]].t()            # [Y, X]
+                    np.testing.assert_array_equal(t2c[ph * 2 + pw, :, ty * 2 + tx, :].numpy(), ref.numpy())
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('shape', SHAPES)
+def test_conv_forward_s2(dtype, shape):
+    """S2 geometry == nn.Conv2d(k4,s2,p1) forward (unetbaseline_model.py:187)."""
+    B, C0, C1, N, Hs = shape
+    torch.manual_seed(1)
+    x = rounded(torch.randn(B, C0 + C1, 2 * Hs, 2 * Hs), dtype)
+    w = rounded(torch.randn(N, C0 + C1, 4, 4) * 0.1, dtype)
+    ref = F.conv2d(x, w, stride=2, padding=1)
+    s2, _ = pack(w, dtype)
+    in0 = nhwc(x[:, :C0], dtype)
+    in1 = nhwc(x[:, C0:], dtype) if C1 else None
+    out = torch.empty(B, Hs, Hs, N, dtype=torch.float32, device=DEV)
+    _, ws = ws_for(dtype, 0, B, Hs, Hs, C0, C1, N, [N])
+    k = K()
+    k.igemm(dtype, 0, B, Hs, Hs, in0, in1, s2, N, 0, [k.Seg(N, out0=out)], ws)
+    assert rel_err(from_nhwc(out), ref) <= TOL_F32_OUT[dtype]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('shape', SHAPES)
+def test_convT_forward_t2(dtype, shape):
+    """T2 geometry == nn.ConvTranspose2d(k4,s2,p1) forward (unetbaseline_model.py:196-220)."""
+    B, C0, C1, N, Hs = shape
+    torch.manual_seed(2)
+    x = rounded(torch.randn(B, C0 + C1, Hs, Hs), dtype)
+    w = rounded(torch.randn(C0 + C1, N, 4, 4) * 0.1, dtype)
+    ref = F.conv_transpose2d(x, w, stride=2, padding=1)
+    _, t2 = pack(w, dtype)
+    in0 = nhwc(x[:, :C0], dtype)
+    in1 = nhwc(x[:, C0:], dtype) if C1 else None
+    out = torch.empty(B, 2 * Hs, 2 * Hs, N, dtype=torch.float32, device=DEV)
+    _, ws = ws_for(dtype, 1, B, Hs, Hs, C0, C1, N, [N])
+    k = K()
+    k.igemm(dtype, 1, B, Hs, Hs, in0, in1, t2, N, 0, [k.Seg(N, out0=out)], ws)
+    assert rel_err(from_nhwc(out), ref) <= TOL_F32_OUT[dtype]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('shape', SHAPES)
+def test_conv_dgrad_and_convT_dgrad(dtype, shape):
+    """conv dgrad = T2 with the conv's phase-packed weights; convT dgrad = S2 with the convT's s2 pack."""
+    B, C0, C1, N, Hs = shape
+    C = C0 + C1
+    torch.manual_seed(3)
+    k = K()
+    # conv: y = conv2d(x[B,C,2Hs,2Hs], w[N,C,4,4]); dX = conv_transpose2d(dY, w)
+    w = rounded(torch.randn(N, C, 4, 4) * 0.1, dtype)
+    dy = rounded(torch.randn(B, N, Hs, Hs), dtype)
+    ref = F.conv_transpose2d(dy, w, stride=2, padding=1)
+    _, t2 = pack(w, dtype)                      # [4][C][4][N]
+    out = torch.empty(B, 2 * Hs, 2 * Hs, C, dtype=torch.float32, device=DEV)
+    _, ws = ws_for(dtype, 1, B, Hs, Hs, N, 0, C, [C])
+    k.igemm(dtype, 1, B, Hs, Hs, nhwc(dy, dtype), None, t2, C, 0, [k.Seg(C, out0=out)], ws)
+    assert rel_err(from_nhwc(out), ref) <= TOL_F32_OUT[dtype]
+    # convT: z = conv_transpose2d(a[B,C,Hs,Hs], wt[C,N,4,4]); dA = conv2d(dZ, wt as [out=C,in=N])
+    wt = rounded(torch.randn(C, N, 4, 4) * 0.1, dtype)
+    dz = rounded(torch.randn(B, N, 2 * Hs, 2 * Hs), dtype)
+    ref2 = F.conv2d(dz, wt, stride=2, padding=1)
+    s2, _ = pack(wt, dtype)                     # [C][16][N]
+    out2 = torch.empty(B, Hs, Hs, C, dtype=torch.float32, device=DEV)
+    _, ws2 = ws_for(dtype, 0, B, Hs, Hs, N, 0, C, [C])
+    k.igemm(dtype, 0, B, Hs, Hs, nhwc(dz, dtype), None, s2, C, 0, [k.Seg(C, out0=out2)], ws2)
+    assert rel_err(from_nhwc(out2), ref2) <= TOL_F32_OUT[dtype]
+
+
+WG_SHAPES = [
+    (2, 128, 0, 64, 8),      # MFMA: R=128, C=64 (two taps per column tile)
+    (2, 128, 128, 128, 4),   # MFMA: two plain sources (convT input = virtual concat)
+    (2, 8, 0, 6, 4),         # generic
+    (1, 4, 4, 1, 8),         # generic, two plain sources, single gathered channel (outermost convT)
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('shape', WG_SHAPES)
+def test_wgrad(dtype, shape):
+    """dW of Conv2d (plain=dZ small grid, gathered=input large grid) and of ConvTranspose2d
+    (plain=input small grid, gathered=dZ large grid) against torch autograd."""
+    B, R0, R1, Cg, Hs = shape
+    R = R0 + R1
+    torch.manual_seed(4)
+    k = K()
+    # conv-style: weight [R, Cg, 4, 4]
+    x = rounded(torch.randn(B, Cg, 2 * Hs, 2 * Hs), dtype)
+    dz = rounded(torch.randn(B, R, Hs, Hs), dtype)
+    w = torch.zeros(R, Cg, 4, 4, requires_grad=True)
+    F.conv2d(x, w, stride=2, padding=1).backward(dz)
+    ref = w.grad.permute(0, 2, 3, 1).reshape(R, 16, Cg)
+    dw = torch.empty(R, 16, Cg, dtype=torch.float32, device=DEV)
+    nbytes = k.wgrad_workspace_bytes(dtype, B, Hs, Hs, R0, R1, Cg, 0)
+    ws = torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=DEV)
+    p0 = nhwc(dz[:, :R0], dtype)
+    p1 = nhwc(dz[:, R0:], dtype) if R1 else None
+    k.wgrad(dtype, B, Hs, Hs, p0, p1, nhwc(x, dtype), None, dw, ws)
+    assert rel_err(dw, ref) <= TOL_F32_OUT[dtype]
+    # convT-style: weight [R(in), Cg(out), 4, 4]; plain = layer input on the small grid
+    a = rounded(torch.randn(B, R, Hs, Hs), dtype)
+    dzl = rounded(torch.randn(B, Cg, 2 * Hs, 2 * Hs), dtype)
+    wt = torch.zeros(R, Cg, 4, 4, requires_grad=True)
+    F.conv_transpose2d(a, wt, stride=2, padding=1).backward(dzl)
+    ref2 = wt.grad.permute(0, 2, 3, 1).reshape(R, 16, Cg)
+    a0 = nhwc(a[:, :R0], dtype)
+    a1 = nhwc(a[:, R0:], dtype) if R1 else None
+    k.wgrad(dtype, B, Hs, Hs, a0, a1, nhwc(dzl, dtype), None, dw, ws)
+    assert rel_err(dw, ref2) <= TOL_F32_OUT[dtype]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(2, 64, 0, 128, 16), (3, 128, 0, 128, 2), (2, 6, 0, 10, 4), (8, 64, 0, 128, 64)])
+def test_epilogue_z_stats_and_bn(dtype, shape):
+    """Z_STATS epilogue + adn_bn_fwd_finalize + adn_bn_act == conv -> BatchNorm2d(train) -> LeakyReLU / ReLU."""
+    B, C0, _, N, Hs = shape
+    torch.manual_seed(5)
+    k = K()
+    x = rounded(torch.randn(B, C0, 2 * Hs, 2 * Hs), dtype)
+    w = rounded(torch.randn(N, C0, 4, 4) * 0.1, dtype)
+    gamma, beta = torch.rand(N) + 0.5, torch.randn(N) * 0.1
+    rm, rv = torch.randn(N) * 0.1, torch.rand(N) + 0.5
+    zref = F.conv2d(x, w, stride=2, padding=1)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    yref = F.batch_norm(zref, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5)
+    s2, _ = pack(w, dtype)
+    P, ws = ws_for(dtype, 0, B, Hs, Hs, C0, 0, N, [N])
+    z = torch.empty(B, Hs, Hs, N, dtype=dtype, device=DEV)
+    partials = torch.zeros(P, 2, N, dtype=torch.float32, device=DEV)
+    k.igemm(dtype, 0, B, Hs, Hs, nhwc(x, dtype), None, s2, N, 1, [k.Seg(N, out0=z, partials=partials)], ws)
+    assert rel_err(from_nhwc(z), zref) <= TOL_T_OUT[dtype]
+    cnt = B * Hs * Hs
+    s1 = partials[:, 0].double().sum(0).cpu()
+    assert rel_err(s1.float(), zref.sum((0, 2, 3))) <= 1e-4 + TOL_F32_OUT[dtype]
+    dev = lambda t: t.to(DEV)
+    mean, istd, scale, shift = [torch.empty(N, device=DEV) for _ in range(4)]
+    rm_d, rv_d = dev(rm.clone()), dev(rv.clone())
+    nbt = torch.zeros(1, dtype=torch.int64, device=DEV)
+    k.bn_fwd_finalize(partials, P, N, cnt, dev(gamma), dev(beta), 1e-5, 0.1, rm_d, rv_d, nbt, mean, istd, scale, shift)
+    assert rel_err(rm_d, rm_ref) <= 1e-4 and rel_err(rv_d, rv_ref) <= 1e-4 and int(nbt.item()) == 1
+    leaky = torch.empty_like(z)
+    relu = torch.empty_like(z)
+    k.bn_act(z, cnt, N, scale, shift, 0.2, leaky, relu)
+    assert rel_err(from_nhwc(leaky), F.leaky_relu(yref, 0.2)) <= 3 * TOL_T_OUT[dtype]
+    assert rel_err(from_nhwc(relu), F.relu(yref)) <= 3 * TOL_T_OUT[dtype]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(2, 128, 0, 64, 8), (2, 10, 0, 6, 4), (8, 128, 0, 64, 64)])
+def test_epilogue_bwd_two_segments(dtype, shape):
+    """convT dgrad with ReLU mask, split into a skip segment (no stats) and an up segment (BN-bwd stats),
+    then accumulate a second contribution with a LeakyReLU mask."""
+    B, Cz, _, Chalf, Hs = shape          # dZ channels, each segment has Chalf channels
+    Cin = 2 * Chalf
+    torch.manual_seed(6)
+    k = K()
+    wt = rounded(torch.randn(Cin, Cz, 4, 4) * 0.1, dtype)
+    dz = rounded(torch.randn(B, Cz, 2 * Hs, 2 * Hs), dtype)
+    dA = F.conv2d(dz, wt, stride=2, padding=1)                       # [B, Cin, Hs, Hs]
+    ref_act = [rounded(torch.randn(B, Chalf, Hs, Hs), dtype) for _ in range(2)]   # activated fwd tensors
+    zfwd = rounded(torch.randn(B, Chalf, Hs, Hs), dtype)
+    mean, istd = torch.randn(Chalf) * 0.1, torch.rand(Chalf) + 0.5
+    g0_ref = dA[:, :Chalf] * (ref_act[0] > 0).float()
+    g1_ref = dA[:, Chalf:] * (ref_act[1] > 0).float()
+    xhat = (zfwd - mean.view(1, -1, 1, 1)) * istd.view(1, -1, 1, 1)
+    s2, _ = pack(wt, dtype)
+    P, ws = ws_for(dtype, 0, B, Hs, Hs, Cz, 0, Cin, [Chalf, Chalf])
+    g0 = torch.empty(B, Hs, Hs, Chalf, dtype=dtype, device=DEV)
+    g1 = torch.empty_like(g0)
+    partials = torch.zeros(P, 2, Chalf, dtype=torch.float32, device=DEV)
+    segs = [k.Seg(Chalf, out0=g0, ref=nhwc(ref_act[0], dtype), slope=0.0),
+            k.Seg(Chalf, out0=g1, ref=nhwc(ref_act[1], dtype), z=nhwc(zfwd, dtype), mean=mean.to(DEV),
+                  istd=istd.to(DEV), partials=partials, slope=0.0)]
+    k.igemm(dtype, 0, B, Hs, Hs, nhwc(dz, dtype), None, s2, Cin, 3, segs, ws)
+    assert rel_err(from_nhwc(g0), g0_ref) <= TOL_T_OUT[dtype]
+    assert rel_err(from_nhwc(g1), g1_ref) <= TOL_T_OUT[dtype]
+    assert rel_err(partials[:, 0].sum(0), g1_ref.sum((0, 2, 3))) <= 1e-3
+    assert rel_err(partials[:, 1].sum(0), (g1_ref * xhat).sum((0, 2, 3))) <= 1e-3
+    # second contribution accumulated with a leaky mask (conv dgrad -> T2 geometry)
+    wc = rounded(torch.randn(Cz, Chalf, 4, 4) * 0.1, dtype)          # conv weight [Cout=Cz, Cin=Chalf]
+    dzs = rounded(torch.randn(B, Cz, Hs // 2, Hs // 2), dtype)
+    dX = F.conv_transpose2d(dzs, wc, stride=2, padding=1)            # [B, Chalf, Hs, Hs]
+    acc_ref = from_nhwc(g0) + dX * torch.where(ref_act[0] > 0, 1.0, 0.2)
+    _, t2 = pack(wc, dtype)
+    P2, ws2 = ws_for(dtype, 1, B, Hs // 2, Hs // 2, Cz, 0, Chalf, [Chalf])
+    k.igemm(dtype, 1, B, Hs // 2, Hs // 2, nhwc(dzs, dtype), None, t2, Chalf, 3,
+            [k.Seg(Chalf, out0=g0, ref=nhwc(ref_act[0], dtype), slope=0.2, accumulate=True)], ws2)
+    assert rel_err(from_nhwc(g0), acc_ref) <= 2 * TOL_T_OUT[dtype]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_bn_backward_pieces(dtype):
+    """adn_bn_bwd_finalize + adn_bn_bwd_apply == BatchNorm2d(train) backward."""
+    torch.manual_seed(7)
+    k = K()
+    B, C, H = 4, 24, 6
+    z = rounded(torch.randn(B, C, H, H), dtype).requires_grad_(True)
+    gamma = (torch.rand(C) + 0.5).requires_grad_(True)
+    beta = torch.zeros(C, requires_grad=True)
+    y = F.batch_norm(z, None, None, gamma, beta, True, 0.1, 1e-5)
+    g = rounded(torch.randn(B, C, H, H), dtype)
+    y.backward(g)
+    zd = z.detach()
+    mu = zd.mean((0, 2, 3))
+    var = zd.var((0, 2, 3), unbiased=False)
+    istd = 1.0 / torch.sqrt(var + 1e-5)
+    xhat = (zd - mu.view(1, -1, 1, 1)) * istd.view(1, -1, 1, 1)
+    cnt = B * H * H
+    partials = torch.stack([g.sum((0, 2, 3)), (g * xhat).sum((0, 2, 3))]).view(1, 2, C).to(DEV)
+    dgamma, dbeta = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    coef = torch.empty(2 * C, device=DEV)
+    k.bn_bwd_finalize(partials, 1, C, cnt, dgamma, dbeta, coef)
+    assert rel_err(dgamma, gamma.grad) <= 1e-4 and rel_err(dbeta, beta.grad) <= 1e-4
+    gd = nhwc(g, dtype)
+    k.bn_bwd_apply(gd, nhwc(zd, dtype), cnt, C, (gamma.detach() * istd).to(DEV), mu.to(DEV), istd.to(DEV), coef)
+    assert rel_err(from_nhwc(gd), z.grad) <= 2 * TOL_T_OUT[dtype]
+
+
+def test_layout_roundtrip():
+    k = K()
+    x = torch.randn(2, 3, 5, 7, device=DEV)
+    for dt in (torch.float32, torch.bfloat16):
+        y = torch.empty(2, 5, 7, 3, dtype=dt, device=DEV)
+        k.nchw_to_nhwc(x, y)
+        assert torch.equal(y, x.permute(0, 2, 3, 1).to(dt))
+        back = torch.empty_like(x)
+        k.nhwc_to_nchw(y, back)
+        assert torch.equal(back, x.to(dt).float())
+
+
+def test_missing_gpu_tensor_fails_loudly():
+    k = K()
+    with pytest.raises(RuntimeError):
+        k.nchw_to_nhwc(torch.randn(1, 1, 2, 2), torch.empty(1, 2, 2, 1))
