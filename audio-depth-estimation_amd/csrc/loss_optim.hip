@@ -20,7 +20,9 @@ __device__ __forceinline__ double block_sum_d(double v, double* sh) {
   return t;
 }
 
-__device__ __forceinline__ bool valid_px(float g, int mask_mode) { return mask_mode == 0 ? (g != 0.0f) : (g > 0.0f); }
+__device__ __forceinline__ bool valid_px(float g, int mask_mode) {
+  return mask_mode == 0 ? (g != 0.0f) : (mask_mode == 1 ? (g > 0.0f) : true);
+}
 
 __global__ __launch_bounds__(256) void loss_stats_partial_kernel(const float* pred, const float* gt, int64_t n,
                                                                  float scale, int mask_mode, float eps,
@@ -237,7 +239,7 @@ extern "C" int64_t adn_loss_workspace_bytes(int64_t n) { return (int64_t)red_blo
 extern "C" int adn_loss_stats(const float* pred, const float* gt, int64_t n, float scale, int32_t mask_mode,
                               float eps, double* stats, void* workspace, int64_t workspace_bytes, void* stream) {
   ADN_CHECK_ARG(pred && gt && n > 0 && stats && workspace, "adn_loss_stats: bad arguments");
-  ADN_CHECK_ARG(mask_mode == 0 || mask_mode == 1, "adn_loss_stats: bad mask_mode %d", mask_mode);
+  ADN_CHECK_ARG(mask_mode >= 0 && mask_mode <= 2, "adn_loss_stats: bad mask_mode %d", mask_mode);
   const unsigned nb = red_blocks(n);
   ADN_CHECK_ARG(workspace_bytes >= (int64_t)nb * 32, "adn_loss_stats: workspace too small");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -254,6 +256,7 @@ extern "C" int adn_loss_finish(const float* pred, const float* gt, int64_t n, fl
                                float silog_lambda, float* loss_out, float* grad, void* stream) {
   ADN_CHECK_ARG(pred && gt && n > 0 && stats, "adn_loss_finish: bad arguments");
   ADN_CHECK_ARG(criterion >= 0 && criterion <= 2, "adn_loss_finish: bad criterion %d", criterion);
+  ADN_CHECK_ARG(mask_mode >= 0 && mask_mode <= 2, "adn_loss_finish: bad mask_mode %d", mask_mode);
   ADN_CHECK_ARG(loss_out || grad, "adn_loss_finish: nothing to compute");
   int64_t nb = grad ? adn_cdiv(n, 256) : 1;
   if (nb > 4096) nb = 4096;

@@ -23,6 +23,28 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# Optional per-launch timing of the GEMM kernels (bench.py): when PROFILE is a list, every igemm/wgrad
+# launch appends (label, algorithmic_flops, start_event, end_event); events are recorded on the stream the
+# kernel is launched on (torch's current stream), nothing synchronises.
+PROFILE = None
+
+
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record()
+    return ev
+
+
+def _prof_end(ev0, label, flops):
+    if ev0 is None:
+        return
+    ev1 = torch.cuda.Event(enable_timing=True)
+    ev1.record()
+    PROFILE.append((label, flops, ev0, ev1))
+
+
 def dtype_code(dt: torch.dtype) -> int:
     if dt == torch.float32:
         return ADN_F32
@@ -94,7 +116,10 @@ def igemm_query(dtype, geom, B, Hs, Ws, C0, C1, N, seg_channels):
 
 def igemm(dtype, geom, B, Hs, Ws, in0, in1, w, N, epi, segs, workspace=None):
     d = _igemm_desc(dtype, geom, B, Hs, Ws, in0, in1, w, N, epi, segs, workspace)
+    ev = _prof_begin()
     _lib.call('adn_igemm', C.byref(d), _stream())
+    if ev is not None:     # 2*M_out*N*K, K = taps*Cin  (S2: 16 taps on B*Hs*Ws pixels; T2: 4 taps on 4x the pixels)
+        _prof_end(ev, 'igemm', 2.0 * B * Hs * Ws * N * 16 * (d.C0 + d.C1))
 
 
 def _wgrad_desc(dtype, B, Hs, Ws, plain0, plain1, gath0, gath1, dw, workspace):
@@ -128,7 +153,10 @@ def wgrad_workspace_bytes(dtype, B, Hs, Ws, R0, R1, C0, C1):
 
 def wgrad(dtype, B, Hs, Ws, plain0, plain1, gath0, gath1, dw, workspace=None):
     d = _wgrad_desc(dtype, B, Hs, Ws, plain0, plain1, gath0, gath1, dw, workspace)
+    ev = _prof_begin()
     _lib.call('adn_wgrad', C.byref(d), _stream())
+    if ev is not None:
+        _prof_end(ev, 'wgrad', 2.0 * B * Hs * Ws * (d.R0 + d.R1) * 16 * (d.C0 + d.C1))
 
 
 def pack_weights(master, X, Y, dtype, s2_out=None, t2_out=None):

@@ -1,0 +1,178 @@
+"""Headline benchmark: depth-maps/s of a full U-Net train step on synthetic BatVisionV2-shaped batches.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload = BASELINE.json configs[1]: models.unetbaseline_model.define_G(unet_256, ngf 64) on 256x256
+two-channel inputs, bf16 MFMA compute, batch 32 PER GPU (weak scaling), one step = forward + masked
+Combined loss (conf/mode/train.yaml weights) + backward + [gradient all-reduce] + clip_grad_norm(1.0) +
+AdamW -- exactly /root/reference/train.py:633-691.  Inputs are resident in HBM when the timed region starts.
+Rank 0 prints ONE JSON line; it also carries
+  roofline:     the dominant kernel family (MFMA implicit GEMM) timed with HIP events on its own stream
+                inside the timed region, algorithmic FLOPs / time vs the bf16 dense MFMA peak;
+  cpu_baseline: the CPU oracle (port of the reference's torch-CPU path) timed on this box's host cores
+                on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_PEAK_TF = {'bf16': 2500.0, 'f32': 157.3}      # MI355X_MICROARCH.md, dense
+L1_W, SILOG_W, SILOG_LAMBDA, LR = 0.237, 0.637, 0.869, 0.002   # conf/mode/train.yaml
+
+
+def synth_batch(B, S, seed, device):
+    """audio ~ U[0,1) (mel min-max range), depth 30*U with <3 m invalid."""
+    g = torch.Generator().manual_seed(seed)
+    audio = torch.rand(B, 2, S, S, generator=g)
+    gt = 30.0 * torch.rand(B, 1, S, S, generator=g)
+    gt[gt < 3.0] = 0.0
+    return audio.to(device), gt.to(device)
+
+
+def cpu_baseline(B, steps, warmup):
+    """Reference CPU path restated by oracle/ (fwd + loss + bwd through torch autograd, then the same
+    clip_grad_norm_ / AdamW the reference calls), all host cores, fp32."""
+    from oracle import loss_oracle, unet_oracle
+    from audio_depth_estimation_amd.models.unetbaseline_model import define_G
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = SimpleNamespace(dataset=SimpleNamespace(depth_norm=False, max_depth=30.0))
+    torch.manual_seed(0)
+    model = define_G(cfg, 2, 1, 64, 'unet_256')
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    pkeys = unet_oracle.param_keys(8)
+    params = [sd[k].requires_grad_(True) for k in pkeys]
+    opt = torch.optim.AdamW(params, lr=LR)
+    times = []
+    for it in range(warmup + steps):
+        audio, gt = synth_batch(B, 256, 1234 + it, 'cpu')
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        pred, stats = unet_oracle.unet_forward(sd, audio, 8, False, training=True)
+        loss = loss_oracle.masked_loss(pred, gt, 'Combined', L1_W, SILOG_W, SILOG_LAMBDA)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+        for k, v in stats.items():
+            sd[k] = v
+        dt = time.perf_counter() - t0
+        if it >= warmup:
+            times.append(dt)
+    times.sort()
+    med = times[len(times) // 2]
+    return {'value': B / med, 'unit': 'depth-maps/s', 'cores': cores, 'kind': 'port',
+            'sample': f'unet_256 ngf64 fp32 B={B} 256x256, median of {steps} train steps after {warmup} warm-up, '
+                      f'torch {torch.__version__} CPU, {cores} threads'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32, help='per-GPU batch')
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-batch', type=int, default=8)
+    ap.add_argument('--cpu-steps', type=int, default=5)
+    args = ap.parse_args()
+
+    from audio_depth_estimation_amd import ddp as addp
+    from audio_depth_estimation_amd import kernels as K
+    from audio_depth_estimation_amd.engine import FusedTrainer
+    from audio_depth_estimation_amd.models.unetbaseline_model import define_G
+
+    rank, world, local = addp.init_from_env('nccl')
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N > 1')
+    device = torch.device('cuda', local)
+    torch.cuda.set_device(device)
+    dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+
+    cfg = SimpleNamespace(dataset=SimpleNamespace(depth_norm=False, max_depth=30.0))
+    torch.manual_seed(0)
+    model = define_G(cfg, 2, 1, 64, 'unet_256')
+    model.compute_dtype = dtype
+    model = model.to(device).train()
+    reducer = addp.GradientAllReducer() if world > 1 else None
+    trainer = FusedTrainer(model.engine(), 'Combined', L1_W, SILOG_W, SILOG_LAMBDA, max_depth=30.0,
+                           optimizer='AdamW', lr=LR, clip_norm=1.0, ddp=reducer)
+    B, S = args.batch, 256
+    batches = [synth_batch(B, S, 1234 + 1000 * rank + i, device) for i in range(4)]
+    if reducer is not None:
+        model.engine().bind_parameters()
+        reducer.broadcast_parameters(model.engine().flat_p)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        trainer.step(*batches[i % len(batches)])
+    barrier()
+    K.PROFILE = []                      # HIP events around every GEMM launch of the timed region
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss, _ = trainer.step(*batches[i % len(batches)])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof, K.PROFILE = K.PROFILE, None
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    final_loss = float(loss.item())
+
+    if rank == 0:
+        fam = {}
+        for label, flops, e0, e1 in prof:
+            acc = fam.setdefault(label, [0.0, 0.0, 0])
+            acc[0] += flops
+            acc[1] += e0.elapsed_time(e1) * 1e-3
+            acc[2] += 1
+        dom = max(fam, key=lambda k: fam[k][1])
+        flops, secs, launches = fam[dom]
+        achieved = flops / secs / 1e12
+        peak = MFMA_PEAK_TF[args.dtype]
+        gemm_secs = sum(v[1] for v in fam.values())
+        result = {
+            'metric': 'depth-maps/sec (train step)', 'value': world * B * args.steps / elapsed,
+            'unit': 'depth-maps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': 'unetbaseline_model unet_256 (ngf 64) train step, BatVisionV2-shaped 256x256, '
+                                   f'batch {B}/GPU, Combined L1+SIlog loss, clip 1.0, AdamW',
+                       'global_batch': world * B, 'image_size': S,
+                       'parallelism': f'dp{world}' + (' (RCCL bucketed grad all-reduce)' if world > 1 else '')},
+            'roofline': {'bound': 'mfma', 'kernel': {'igemm': 'igemm_mfma_kernel', 'wgrad': 'wgrad_mfma_kernel'}[dom],
+                         'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
+                         'traffic': None, 'launches': launches,
+                         'avg_launch_ms': 1e3 * secs / launches,
+                         'gemm_share_of_step': gemm_secs / elapsed,
+                         'all_gemm_tflops': sum(v[0] for v in fam.values()) / gemm_secs / 1e12},
+            'final_loss': final_loss,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result['cpu_baseline'] = cpu_baseline(args.cpu_batch, args.cpu_steps, 2)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -154,7 +154,8 @@ int adn_bn_bwd_apply(void* g, const void* z, int64_t pixels, int32_t C, int32_t 
                      void* stream);
 
 /* Masked depth loss (train.py:646-669, utils_loss.py:29-49).
- * stats[0..4) (f64) = N, sum|p-g|, sum d, sum d^2 over valid pixels; mask_mode 0: gt != 0, 1: gt > 0.
+ * stats[0..4) (f64) = N, sum|p-g|, sum d, sum d^2 over valid pixels; mask_mode 0: gt != 0, 1: gt > 0,
+ * 2: every element (inputs already gathered, utils_loss.py call sites).
  * adn_loss_stats zeroes nothing: it overwrites stats.  A data-parallel caller all-reduces stats
  * (4 doubles) between the two calls to reproduce the reference's single global-batch loss. */
 int adn_loss_stats(const float* pred, const float* gt, int64_t n, float scale, int32_t mask_mode,

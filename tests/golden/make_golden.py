@@ -40,12 +40,19 @@ def synth_batch(B, C, S, seed, max_depth=30.0, depth_norm=False):
     return audio, gt
 
 
-def unet_case(name, netG, ngf, S, depth_norm, max_depth, criterion, B=2, lr=0.002):
+def unet_case(name, netG, ngf, S, depth_norm, max_depth, criterion, B=2, lr=0.002, out_bias=None, wscale=1.0):
     cfg = SimpleNamespace(dataset=SimpleNamespace(depth_norm=depth_norm, max_depth=max_depth))
     torch.manual_seed(0)
     model = define_G(cfg, input_nc=2, output_nc=1, ngf=ngf, netG=netG, norm='batch',
                      use_dropout=False, init_type='normal', init_gain=0.02, gpu_ids=[])
     out = {}
+    out['sd_init/model.model.0.weight'] = model.state_dict()['model.model.0.weight'].clone().numpy()
+    if out_bias is not None:
+        # A freshly initialised ReLU head predicts ~0 m, where SIlog's 1/pred makes d loss/d pred
+        # ill-conditioned (a 5e-7 change of pred moves the gradient by 1%).  Shift the outermost bias so
+        # the vectors test the kernels, not the conditioning of log() near 0.
+        with torch.no_grad():
+            model.model.model[3].bias.fill_(out_bias)
     sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
     for k, v in sd0.items():
         out['sd0/' + k] = v.numpy()
@@ -69,12 +76,14 @@ def unet_case(name, netG, ngf, S, depth_norm, max_depth, criterion, B=2, lr=0.00
     l1 = torch.nn.L1Loss()
     silog = SIlogLoss(lambda_scale=SILOG_LAMBDA)
     if criterion == 'Combined':
-        loss = L1_W * l1(p, g) + SILOG_W * silog(p, g)              # train.py:656-658
+        loss = wscale * L1_W * l1(p, g) + wscale * SILOG_W * silog(p, g)   # train.py:656-658
     elif criterion == 'L1':
         loss = l1(p, g)
     else:
         loss = silog(p, g)
+    pred.retain_grad()
     loss.backward()
+    out['pred_grad'] = pred.grad.detach().clone().numpy()
     out['pred_train'] = pred.detach().numpy()
     out['loss'] = np.float64(loss.item())
     for k, prm in model.named_parameters():
@@ -85,7 +94,7 @@ def unet_case(name, netG, ngf, S, depth_norm, max_depth, criterion, B=2, lr=0.00
     for k, v in model.state_dict().items():
         out['sd1/' + k] = v.detach().clone().numpy()
     out['meta'] = np.array([ngf, S, int(depth_norm), B], dtype=np.int64)
-    out['hyper'] = np.array([lr, max_depth, L1_W, SILOG_W, SILOG_LAMBDA], dtype=np.float64)
+    out['hyper'] = np.array([lr, max_depth, wscale * L1_W, wscale * SILOG_W, SILOG_LAMBDA], dtype=np.float64)
     np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
     print(name, 'loss', loss.item(), 'grad_norm', total_norm.item(),
           'bytes', os.path.getsize(os.path.join(HERE, name + '.npz')))
@@ -174,7 +183,7 @@ def optim_cases():
 
 if __name__ == '__main__':
     torch.set_num_threads(8)
-    unet_case('unet256_ngf4', 'unet_256', 4, 256, False, 30.0, 'Combined')
+    unet_case('unet256_ngf4', 'unet_256', 4, 256, False, 30.0, 'Combined', out_bias=1.0, wscale=10.0)   # 10x loss weights (--l1_weight/--silog_weight) so that the clip branch fires
     unet_case('unet128_ngf4_dn', 'unet_128', 4, 128, True, 12.0, 'Combined')
     loss_cases()
     metrics_cases()

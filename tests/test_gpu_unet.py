@@ -1,0 +1,187 @@
+"""GPU parity of the fused U-Net pipeline (models.unetbaseline_model on libadn).
+
+  * against the committed golden vectors produced by the REFERENCE (tests/golden/unet*.npz; ngf=4 so every
+    layer runs the generic HIP kernels) -- f32 compute, tolerance: relative L1 of the prediction <= 1e-4
+    (north_star), gradients <= 2e-3 of the per-tensor max, one clipped AdamW step <= 1e-4;
+  * against the CPU oracle evaluated in float64 at the full width ngf=64 (MFMA kernels).  float64 because
+    torch-CPU fp32 itself is ~1e-3 off the fp64 gradients at this depth while the exact-f32 MFMA path is
+    ~3e-5 off (measured): f32 tolerance: prediction relative L1 <= 1e-5, gradients <= 2e-4 of the tensor max.
+    bf16 has no reference counterpart; stated here: prediction relative L1 <= 1e-2, loss <= 1e-3,
+    gradient cosine >= 0.93 per tensor at B=2 (BatchNorm over 8 values at the bottleneck amplifies bf16
+    rounding; see DESIGN.md for the measured values at larger batch).
+"""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+DEV = 'cuda'
+
+
+def _cfg(depth_norm, max_depth=30.0):
+    return SimpleNamespace(dataset=SimpleNamespace(depth_norm=bool(depth_norm), max_depth=max_depth))
+
+
+def _build(netG, ngf, depth_norm, dtype, sd=None, gpu_ids=()):
+    from audio_depth_estimation_amd.models.unetbaseline_model import define_G
+    model = define_G(_cfg(depth_norm), 2, 1, ngf, netG, gpu_ids=list(gpu_ids))
+    core = model.module if hasattr(model, 'module') else model
+    core.compute_dtype = dtype
+    if sd is not None:
+        model.load_state_dict(sd)
+    return model.to(DEV)
+
+
+def rel_l1(a, b):
+    a, b = a.detach().float().cpu(), torch.as_tensor(b).float()
+    return float((a - b).abs().sum() / (b.abs().sum() + 1e-30))
+
+
+def max_rel(a, b):
+    a, b = a.detach().float().cpu(), torch.as_tensor(b).float()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.mark.parametrize('name,netG', [('unet256_ngf4', 'unet_256'), ('unet128_ngf4_dn', 'unet_128')])
+def test_golden_reference_parity_f32(name, netG):
+    from audio_depth_estimation_amd.engine import FusedTrainer
+    z = np.load(os.path.join(GOLDEN, name + '.npz'))
+    ngf, S, depth_norm, B = [int(v) for v in z['meta']]
+    lr, max_depth, l1w, sw, lam = [float(v) for v in z['hyper']]
+    sd0 = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('sd0/')}
+    model = _build(netG, ngf, depth_norm, torch.float32, sd0)
+    assert list(model.state_dict().keys()) == list(sd0.keys())
+    audio, gt = torch.from_numpy(z['audio']).to(DEV), torch.from_numpy(z['gt']).to(DEV)
+
+    model.eval()
+    with torch.no_grad():
+        pe = model(audio)
+    assert rel_l1(pe, z['pred_eval']) <= 1e-4
+
+    # --- path 1: torch autograd + torch optimizer driving the fused engine (drop-in train.py semantics)
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=lr)
+    opt.zero_grad()
+    pred = model(audio)
+    assert rel_l1(pred, z['pred_train']) <= 1e-4
+    valid = gt != 0
+    scale = max_depth if depth_norm else 1.0
+    p, g = pred[valid] * scale, gt[valid] * scale
+    d = torch.log(torch.clamp(p, min=1e-6)) - torch.log(torch.clamp(g, min=1e-6))
+    loss = l1w * (p - g).abs().mean() + sw * torch.sqrt(torch.clamp((d * d).mean() - lam * d.mean() ** 2, min=0))
+    assert abs(loss.item() - float(z['loss'])) <= 1e-4 * abs(float(z['loss']))
+    pred.retain_grad()
+    loss.backward()
+    assert max_rel(pred.grad, z['pred_grad']) <= 1e-4
+    for k, prm in model.named_parameters():
+        ref = z['grad/' + k]
+        assert prm.grad is not None, k
+        assert max_rel(prm.grad, ref) <= 2e-3, k
+    tn = torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+    assert abs(tn.item() - float(z['grad_norm'])) <= 1e-3 * float(z['grad_norm'])
+    opt.step()
+    sd1 = model.state_dict()
+    for k in sd1:
+        ref = torch.from_numpy(z['sd1/' + k])
+        if ref.dtype == torch.int64:
+            assert int(sd1[k]) == int(ref), k
+        else:
+            assert float((sd1[k].cpu() - ref).abs().max()) <= 0.02 * lr, k   # 2% of one Adam step
+
+    # --- path 2: fully fused step (loss/clip/AdamW kernels) from the same start point
+    model2 = _build(netG, ngf, depth_norm, torch.float32, sd0)
+    model2.train()
+    tr = FusedTrainer(model2.engine(), 'Combined', l1w, sw, lam, max_depth=max_depth, optimizer='AdamW', lr=lr,
+                      clip_norm=1.0)
+    loss2, pred2 = tr.step(audio, gt)
+    assert abs(loss2.item() - float(z['loss'])) <= 1e-4 * abs(float(z['loss']))
+    assert max_rel(tr.gout, z['pred_grad']) <= 1e-4
+    assert abs(tr.state[3].item() - float(z['grad_norm'])) <= 1e-3 * float(z['grad_norm'])
+    sd2 = model2.state_dict()
+    for k in sd2:
+        ref = torch.from_numpy(z['sd1/' + k])
+        if ref.dtype == torch.int64:
+            assert int(sd2[k]) == int(ref), k
+        else:
+            assert float((sd2[k].cpu() - ref).abs().max()) <= 0.02 * lr, k
+
+
+def _oracle_step(sd, audio, gt, nd, depth_norm, hyper):
+    from oracle import loss_oracle, unet_oracle
+    l1w, sw, lam, max_depth = hyper
+    sd = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    audio, gt = audio.double(), gt.double()
+    pkeys = unet_oracle.param_keys(nd)
+    for k in pkeys:
+        sd[k].requires_grad_(True)
+    pred, stats = unet_oracle.unet_forward(sd, audio, nd, depth_norm, training=True)
+    loss = loss_oracle.masked_loss(pred, gt, 'Combined', l1w, sw, lam, scale=max_depth if depth_norm else 1.0)
+    loss.backward()
+    return pred.detach(), loss.item(), {k: sd[k].grad for k in pkeys}, stats
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_full_width_unet256_against_oracle(dtype):
+    """ngf=64 unet_256 at 256x256, B=2: every conv layer except the two edge layers runs the MFMA kernels."""
+    from audio_depth_estimation_amd.engine import FusedTrainer
+    torch.manual_seed(0)
+    model = _build('unet_256', 64, False, dtype)
+    with torch.no_grad():      # keep predictions away from 0 where SIlog's 1/pred is ill-conditioned
+        model.model.model[3].bias.fill_(1.0)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(1234)
+    audio = torch.rand(2, 2, 256, 256, generator=g)
+    gt = 30 * torch.rand(2, 1, 256, 256, generator=g)
+    gt[gt < 3] = 0
+    hyper = (0.237, 0.637, 0.869, 30.0)
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    pred_ref, loss_ref, grads_ref, stats_ref = _oracle_step(sd, audio, gt, 8, False, hyper)
+
+    model.train()
+    tr = FusedTrainer(model.engine(), 'Combined', *hyper[:3], max_depth=30.0, optimizer='AdamW', lr=0.002,
+                      clip_norm=1.0)
+    eng = model.engine()
+    loss, pred = tr.step(audio.to(DEV), gt.to(DEV))
+    tol_pred = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel_l1(pred, pred_ref) <= tol_pred
+    assert abs(loss.item() - loss_ref) <= (1e-5 if dtype == torch.float32 else 1e-3) * abs(loss_ref)
+    for k, prm in model.named_parameters():
+        got = eng.grad_view(prm).detach().float().cpu().reshape(-1)
+        ref = grads_ref[k].reshape(-1).float()
+        if dtype == torch.float32:
+            assert max_rel(got, ref) <= 2e-4, k
+        else:
+            cos = float(torch.dot(got, ref) / (got.norm() * ref.norm() + 1e-30))
+            assert cos >= 0.93, (k, cos)
+    for k, v in stats_ref.items():
+        got = model.state_dict()[k].cpu()
+        v = v.float()
+        assert float((got - v).abs().max()) <= (1e-5 if dtype == torch.float32 else 2e-2) * float(v.abs().max()) + 1e-6, k
+
+
+def test_same_seed_same_weights_and_keys():
+    """define_G consumes the RNG like the reference: seed 0 reproduces the golden initial state_dict."""
+    z = np.load(os.path.join(GOLDEN, 'unet256_ngf4.npz'))
+    torch.manual_seed(0)
+    from audio_depth_estimation_amd.models.unetbaseline_model import define_G
+    model = define_G(_cfg(False), 2, 1, 4, 'unet_256')
+    for k, v in model.state_dict().items():
+        if k == 'model.model.3.bias':      # the fixture shifts this bias to 1.0 (see make_golden.py)
+            assert float(v) == 0.0
+            continue
+        np.testing.assert_array_equal(v.numpy(), z['sd0/' + k], err_msg=k)
+    wrapped = define_G(_cfg(False), 2, 1, 4, 'unet_256', gpu_ids=[0])
+    assert all(k.startswith('module.') for k in wrapped.state_dict().keys())
+
+
+def test_cpu_input_fails_loudly():
+    from audio_depth_estimation_amd.models.unetbaseline_model import define_G
+    model = define_G(_cfg(False), 2, 1, 4, 'unet_256')
+    with pytest.raises(RuntimeError):
+        model(torch.rand(1, 2, 256, 256))
+    with pytest.raises(NotImplementedError):
+        define_G(_cfg(False), 2, 1, 4, 'resnet_9blocks')
