@@ -43,7 +43,7 @@ class AdnWgradDesc(C.Structure):
         ('dtype', c_int32), ('B', c_int32), ('Hs', c_int32), ('Ws', c_int32),
         ('plain0', c_void_p), ('plain1', c_void_p), ('R0', c_int32), ('R1', c_int32),
         ('gath0', c_void_p), ('gath1', c_void_p), ('C0', c_int32), ('C1', c_int32),
-        ('dw', c_void_p), ('workspace', c_void_p), ('workspace_bytes', c_int64),
+        ('dw', c_void_p), ('workspace', c_void_p), ('workspace_bytes', c_int64), ('c_valid', c_int32),
     ]
 
 
@@ -57,8 +57,9 @@ _PROTOS = {
     'adn_igemm': (C.c_int, [C.POINTER(AdnIgemmDesc), c_void_p]),
     'adn_wgrad_workspace_bytes': (c_int64, [C.POINTER(AdnWgradDesc)]),
     'adn_wgrad': (C.c_int, [C.POINTER(AdnWgradDesc), c_void_p]),
-    'adn_pack_weights': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
-    'adn_nchw_to_nhwc': (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    'adn_pack_weights': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    'adn_nchw_to_nhwc': (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                   c_void_p]),
     'adn_nhwc_to_nchw': (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     'adn_bn_fwd_finalize': (C.c_int, [c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p, c_float, c_float,
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -75,7 +76,10 @@ _PROTOS = {
     'adn_loss_workspace_bytes': (c_int64, [c_int64]),
     'adn_loss_finish': (C.c_int, [c_void_p, c_void_p, c_int64, c_float, c_int32, c_float, c_void_p, c_int32,
                                   c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
-    'adn_final_act_bwd': (C.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
+    'adn_final_act_bwd': (C.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    'adn_convt_n1_workspace_bytes': (c_int64, [c_int32, c_int32, c_int32]),
+    'adn_convt_n1_forward': (C.c_int, [c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32,
+                                       c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
     'adn_sum_to_scalar': (C.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
     'adn_grad_norm': (C.c_int, [c_void_p, c_int64, c_float, c_void_p, c_void_p, c_int64, c_void_p]),
     'adn_grad_norm_workspace_bytes': (c_int64, [c_int64]),

@@ -116,4 +116,19 @@ __device__ __forceinline__ float wave_min(float v) {
   return v;
 }
 
+// ---- one 16x16 MFMA tile step on 16-byte operand chunks (bf16: K=32 in one op; f32: 4 exact K=4 ops) ----
+template <typename T>
+__device__ __forceinline__ void mma_tile(const u32x4_t& a, const u32x4_t& b, f32x4_t& acc) {
+  if constexpr (sizeof(T) == 2) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(&a),
+                                                  *reinterpret_cast<const bf16x8_t*>(&b), acc, 0, 0, 0);
+  } else {
+    // exact f32: lane group q=(lane>>4) holds k = 4q..4q+3 of this 16-wide slice for A and B alike;
+    // MFMA step s contracts element s of every lane group (a permutation of k, same on both sides).
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[s]), __uint_as_float(b[s]), acc, 0, 0, 0);
+  }
+}
+
 static inline int64_t adn_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

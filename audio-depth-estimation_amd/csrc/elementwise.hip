@@ -13,12 +13,20 @@ inline unsigned blocks_for(int64_t n, int per_block = 256) {
   return (unsigned)b;
 }
 
-// master [X][4][4][Y] f32 -> s2 [X][16][Y] (cast), t2 [4][Y][4][X] (phase split)
+// master [X][4][4][Y] f32 -> s2 [X][16][Ypad] (cast, zero padded channels), t2 [4][Y][4][X] (phase split)
 template <typename T>
-__global__ __launch_bounds__(256) void pack_weights_kernel(const float* master, int X, int Y, T* s2, T* t2) {
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* master, int X, int Y, int Ypad, T* s2,
+                                                           T* t2) {
   const int64_t n = (int64_t)X * 16 * Y;
+  if (s2) {
+    const int64_t np = (int64_t)X * 16 * Ypad;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < np; e += (int64_t)gridDim.x * 256) {
+      const int y = (int)(e % Ypad);
+      const int64_t xt = e / Ypad;
+      ElemTraits<T>::store(s2 + e, y < Y ? master[xt * Y + y] : 0.0f);
+    }
+  }
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
-    if (s2) ElemTraits<T>::store(s2 + e, master[e]);
     if (t2) {
       // destination-ordered: e -> (phase, y, t, x)
       const int x = (int)(e % X);
@@ -32,13 +40,14 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* master, 
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* src, T* dst, int B, int C, int64_t HW) {
-  const int64_t n = (int64_t)B * C * HW;
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* src, T* dst, int B, int C, int Cpad,
+                                                           int64_t HW) {
+  const int64_t n = (int64_t)B * Cpad * HW;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
-    const int c = (int)(e % C);
-    const int64_t pix = e / C;
+    const int c = (int)(e % Cpad);
+    const int64_t pix = e / Cpad;
     const int64_t b = pix / HW, hw = pix - b * HW;
-    ElemTraits<T>::store(dst + e, src[(b * C + c) * HW + hw]);
+    ElemTraits<T>::store(dst + e, c < C ? src[(b * C + c) * HW + hw] : 0.0f);
   }
 }
 template <typename T>
@@ -185,35 +194,35 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(T* g, const T* z, int
 
 }  // namespace
 
-extern "C" int adn_pack_weights(const float* master, int32_t X, int32_t Y, int32_t dtype, void* s2_out,
-                                void* t2_out, void* stream) {
-  ADN_CHECK_ARG(master && X > 0 && Y > 0, "adn_pack_weights: bad arguments");
+extern "C" int adn_pack_weights(const float* master, int32_t X, int32_t Y, int32_t y_pad, int32_t dtype,
+                                void* s2_out, void* t2_out, void* stream) {
+  ADN_CHECK_ARG(master && X > 0 && Y > 0 && y_pad >= Y, "adn_pack_weights: bad arguments");
   ADN_CHECK_ARG(dtype == ADN_F32 || dtype == ADN_BF16, "adn_pack_weights: bad dtype %d", dtype);
   ADN_CHECK_ARG(s2_out || t2_out, "adn_pack_weights: no output");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const int64_t n = (int64_t)X * 16 * Y;
+  const int64_t n = (int64_t)X * 16 * y_pad;
   if (dtype == ADN_BF16)
-    hipLaunchKernelGGL((pack_weights_kernel<uint16_t>), dim3(blocks_for(n)), dim3(256), 0, st, master, X, Y,
+    hipLaunchKernelGGL((pack_weights_kernel<uint16_t>), dim3(blocks_for(n)), dim3(256), 0, st, master, X, Y, y_pad,
                        reinterpret_cast<uint16_t*>(s2_out), reinterpret_cast<uint16_t*>(t2_out));
   else
-    hipLaunchKernelGGL((pack_weights_kernel<float>), dim3(blocks_for(n)), dim3(256), 0, st, master, X, Y,
+    hipLaunchKernelGGL((pack_weights_kernel<float>), dim3(blocks_for(n)), dim3(256), 0, st, master, X, Y, y_pad,
                        reinterpret_cast<float*>(s2_out), reinterpret_cast<float*>(t2_out));
   ADN_CHECK_LAUNCH();
   return ADN_OK;
 }
 
-extern "C" int adn_nchw_to_nhwc(const float* src, void* dst, int32_t B, int32_t C, int32_t H, int32_t W,
-                                int32_t dtype, void* stream) {
-  ADN_CHECK_ARG(src && dst && B > 0 && C > 0 && H > 0 && W > 0, "adn_nchw_to_nhwc: bad arguments");
+extern "C" int adn_nchw_to_nhwc(const float* src, void* dst, int32_t B, int32_t C, int32_t c_pad, int32_t H,
+                                int32_t W, int32_t dtype, void* stream) {
+  ADN_CHECK_ARG(src && dst && B > 0 && C > 0 && c_pad >= C && H > 0 && W > 0, "adn_nchw_to_nhwc: bad arguments");
   ADN_CHECK_ARG(dtype == ADN_F32 || dtype == ADN_BF16, "adn_nchw_to_nhwc: bad dtype %d", dtype);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const int64_t n = (int64_t)B * C * H * W;
+  const int64_t n = (int64_t)B * c_pad * H * W;
   if (dtype == ADN_BF16)
     hipLaunchKernelGGL((nchw_to_nhwc_kernel<uint16_t>), dim3(blocks_for(n)), dim3(256), 0, st, src,
-                       reinterpret_cast<uint16_t*>(dst), B, C, (int64_t)H * W);
+                       reinterpret_cast<uint16_t*>(dst), B, C, c_pad, (int64_t)H * W);
   else
     hipLaunchKernelGGL((nchw_to_nhwc_kernel<float>), dim3(blocks_for(n)), dim3(256), 0, st, src,
-                       reinterpret_cast<float*>(dst), B, C, (int64_t)H * W);
+                       reinterpret_cast<float*>(dst), B, C, c_pad, (int64_t)H * W);
   ADN_CHECK_LAUNCH();
   return ADN_OK;
 }

@@ -40,20 +40,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
-template <typename T>
-__device__ __forceinline__ void mma_tile(const u32x4_t& a, const u32x4_t& b, f32x4_t& acc) {
-  if constexpr (sizeof(T) == 2) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(&a),
-                                                  *reinterpret_cast<const bf16x8_t*>(&b), acc, 0, 0, 0);
-  } else {
-    // exact f32: lane group q=(lane>>4) holds k = 4q..4q+3 of this 16-wide slice for A and B alike;
-    // MFMA step s contracts element s of every lane group (a permutation of k, same on both sides).
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[s]), __uint_as_float(b[s]), acc, 0, 0, 0);
-  }
-}
-
 template <typename T, int BN, int GEOM>
 __global__ __launch_bounds__(256, 2) void igemm_mfma_kernel(KParams p) {
   constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
@@ -106,19 +92,24 @@ __global__ __launch_bounds__(256, 2) void igemm_mfma_kernel(KParams p) {
 
   u32x4_t ra[4], rb[BROWS];
 
+  // K is laid out [tap][channel] contiguously, so this thread's 16-byte chunk of K-step s starts at
+  // k0 = s*BK + chunk*EPC; tap and channel follow per thread, which also covers narrow layers
+  // (Cin = 8, 16, 32: several taps inside one K-step) and the two-source virtual concat.
+  const int ktot = (GEOM == ADN_GEMM_S2 ? 16 : 4) * Cin;
   auto load_step = [&](int s) {
-    const int tap = s / p.kpt;
-    const int c0 = (s - tap * p.kpt) * BK;
+    const int k0 = s * BK + chunk * EPC;
+    const int tap = k0 / Cin;
+    const int c = k0 - tap * Cin;
     const T* src;
     int Csrc, coff;
-    if (c0 < p.C0) {
+    if (c < p.C0) {
       src = reinterpret_cast<const T*>(p.in0);
       Csrc = p.C0;
-      coff = c0;
+      coff = c;
     } else {
       src = reinterpret_cast<const T*>(p.in1);
       Csrc = p.C1;
-      coff = c0 - p.C0;
+      coff = c - p.C0;
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -138,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void igemm_mfma_kernel(KParams p) {
       u32x4_t v = {0u, 0u, 0u, 0u};
       if (ok) {
         const int64_t pix = ((int64_t)a_b[j] * H + iy) * W + ix;
-        v = *reinterpret_cast<const u32x4_t*>(src + pix * Csrc + coff + chunk * EPC);
+        v = *reinterpret_cast<const u32x4_t*>(src + pix * Csrc + coff);
       }
       ra[j] = v;
     }
@@ -146,12 +137,8 @@ __global__ __launch_bounds__(256, 2) void igemm_mfma_kernel(KParams p) {
 #pragma unroll
     for (int j = 0; j < BROWS; ++j) {
       const int n = tile_n * BN + lrow + 32 * j;
-      int64_t off;
-      if constexpr (GEOM == ADN_GEMM_S2)
-        off = ((int64_t)n * 16 + tap) * Cin + c0 + chunk * EPC;
-      else
-        off = (((int64_t)phase * p.N + n) * 4 + tap) * Cin + c0 + chunk * EPC;
-      rb[j] = *reinterpret_cast<const u32x4_t*>(w + off);
+      const int64_t row = (GEOM == ADN_GEMM_S2) ? (int64_t)n : ((int64_t)phase * p.N + n);
+      rb[j] = *reinterpret_cast<const u32x4_t*>(w + row * ktot + k0);
     }
   };
   auto store_step = [&](int buf) {
@@ -359,34 +346,45 @@ __global__ __launch_bounds__(256) void igemm_direct_kernel(KParams p) {
 }
 
 // ---- slab reduce + epilogue: v = sum_s slab[s][op*N+n] ----
-// Column mapping: thread = channel, block = RB consecutive output pixels; the per-channel stats of a
-// block need no cross-thread reduction and the partial row index is the block index.
-constexpr int RB = 64;
+// Column mapping: thread = channel, block = rb consecutive output pixels x 256 channels; the per-channel
+// stats of a block need no cross-thread reduction and the partial row index is the row-block index.
+// rb is chosen on the host so that small-M (split-K) layers still fill the chip.
 template <typename T>
-__global__ __launch_bounds__(256) void igemm_reduce_kernel(KParams p, int64_t mout) {
-  const int64_t row0 = (int64_t)blockIdx.x * RB;
+__global__ __launch_bounds__(256) void igemm_reduce_kernel(KParams p, int64_t mout, int rb) {
+  const int64_t row0 = (int64_t)blockIdx.x * rb;
   const int64_t slab_stride = mout * p.N;
-  for (int n = threadIdx.x; n < p.N; n += 256) {
-    const bool in0 = n < p.seg[0].channels;
-    const AdnEpiSeg& sg = in0 ? p.seg[0] : p.seg[1];
-    const int nl = in0 ? n : n - p.seg[0].channels;
-    float s1 = 0.f, s2 = 0.f;
-    for (int r = 0; r < RB; ++r) {
-      const int64_t op = row0 + r;
-      if (op >= mout) break;
-      float v = 0.f;
-      for (int s = 0; s < p.nsplit; ++s) v += p.slab[s * slab_stride + op * p.N + n];
-      epi_scalar<T>(p.epi, sg, op, nl, v, s1, s2);
-    }
-    if (sg.partials && (p.epi == ADN_EPI_Z_STATS || p.epi == ADN_EPI_BWD)) {
-      sg.partials[((int64_t)blockIdx.x * 2 + 0) * sg.channels + nl] = s1;
-      sg.partials[((int64_t)blockIdx.x * 2 + 1) * sg.channels + nl] = s2;
-    }
+  const int n = blockIdx.y * 256 + threadIdx.x;
+  if (n >= p.N) return;
+  const bool in0 = n < p.seg[0].channels;
+  const AdnEpiSeg& sg = in0 ? p.seg[0] : p.seg[1];
+  const int nl = in0 ? n : n - p.seg[0].channels;
+  float s1 = 0.f, s2 = 0.f;
+  for (int r = 0; r < rb; ++r) {
+    const int64_t op = row0 + r;
+    if (op >= mout) break;
+    const float* src = p.slab + op * p.N + n;
+    float v = 0.f;
+#pragma unroll 8
+    for (int s = 0; s < p.nsplit; ++s) v += src[s * slab_stride];
+    epi_scalar<T>(p.epi, sg, op, nl, v, s1, s2);
   }
+  if (sg.partials && (p.epi == ADN_EPI_Z_STATS || p.epi == ADN_EPI_BWD)) {
+    sg.partials[((int64_t)blockIdx.x * 2 + 0) * sg.channels + nl] = s1;
+    sg.partials[((int64_t)blockIdx.x * 2 + 1) * sg.channels + nl] = s2;
+  }
+}
+
+inline int reduce_rows(int64_t mout, int N) {
+  const int64_t cb = adn_cdiv(N, 256);
+  int64_t rb = mout * cb / 1024;
+  if (rb > 64) rb = 64;
+  if (rb < 1) rb = 1;
+  return (int)rb;
 }
 
 struct Plan {
   bool mfma;
+  int rb;
   int bn;
   int nsplit;
   int tiles_m, tiles_n, phases;
@@ -404,7 +402,8 @@ bool make_plan(const AdnIgemmDesc* d, Plan* pl) {
   pl->phases = d->geom == ADN_GEMM_T2 ? 4 : 1;
   pl->mout = msmall * pl->phases;
   const int taps = d->geom == ADN_GEMM_S2 ? 16 : 4;
-  const bool aligned = (d->C0 % bk == 0) && (d->C1 % bk == 0) && (d->N % 64 == 0) &&
+  const int epc = 16 / esz;
+  const bool aligned = (d->C0 % epc == 0) && (d->C1 % epc == 0) && ((taps * Cin) % bk == 0) && (d->N % 64 == 0) &&
                        (d->seg[0].channels % 64 == 0) && (d->seg[1].channels % 64 == 0);
   pl->mfma = aligned;
   if (!aligned) {
@@ -412,15 +411,16 @@ bool make_plan(const AdnIgemmDesc* d, Plan* pl) {
     pl->nsplit = 1;
     pl->tiles_m = pl->tiles_n = 0;
     pl->kpt = pl->ksteps = 0;
-    pl->partial_rows = adn_cdiv(pl->mout, RB);
+    pl->rb = reduce_rows(pl->mout, d->N);
+    pl->partial_rows = adn_cdiv(pl->mout, pl->rb);
     pl->slab_bytes = pl->mout * d->N * 4;
     return true;
   }
   pl->bn = (d->N % 128 == 0 && d->seg[0].channels % 128 == 0) ? 128 : 64;
   pl->tiles_m = (int)adn_cdiv(msmall, BM);
   pl->tiles_n = d->N / pl->bn;
-  pl->kpt = Cin / bk;
-  pl->ksteps = taps * pl->kpt;
+  pl->kpt = 0;
+  pl->ksteps = taps * Cin / bk;
   const int64_t tiles = (int64_t)pl->tiles_m * pl->tiles_n * pl->phases;
   int ns = 1;
   if (tiles < 256) {
@@ -431,8 +431,9 @@ bool make_plan(const AdnIgemmDesc* d, Plan* pl) {
     if (ns < 1) ns = 1;
   }
   pl->nsplit = ns;
+  pl->rb = reduce_rows(pl->mout, d->N);
   if (ns > 1) {
-    pl->partial_rows = adn_cdiv(pl->mout, RB);
+    pl->partial_rows = adn_cdiv(pl->mout, pl->rb);
     pl->slab_bytes = (int64_t)ns * pl->mout * d->N * 4;
   } else {
     pl->partial_rows = (int64_t)pl->tiles_m * pl->phases;
@@ -489,8 +490,9 @@ int run(const AdnIgemmDesc* d, const Plan& pl, hipStream_t st) {
     }
     ADN_CHECK_LAUNCH();
     if (pl.nsplit > 1) {
-      hipLaunchKernelGGL((igemm_reduce_kernel<T>), dim3((unsigned)adn_cdiv(pl.mout, RB)), dim3(256), 0, st, kp,
-                         pl.mout);
+      hipLaunchKernelGGL((igemm_reduce_kernel<T>),
+                         dim3((unsigned)adn_cdiv(pl.mout, pl.rb), (unsigned)adn_cdiv(d->N, 256)), dim3(256), 0, st, kp,
+                         pl.mout, pl.rb);
       ADN_CHECK_LAUNCH();
     }
   } else {
@@ -503,8 +505,9 @@ int run(const AdnIgemmDesc* d, const Plan& pl, hipStream_t st) {
       hipLaunchKernelGGL((igemm_direct_kernel<T, ADN_GEMM_T2>), dim3((unsigned)blocks), dim3(256), 0, st, kp);
     ADN_CHECK_LAUNCH();
     kp.nsplit = 1;
-    hipLaunchKernelGGL((igemm_reduce_kernel<T>), dim3((unsigned)adn_cdiv(pl.mout, RB)), dim3(256), 0, st, kp,
-                       pl.mout);
+    hipLaunchKernelGGL((igemm_reduce_kernel<T>),
+                       dim3((unsigned)adn_cdiv(pl.mout, pl.rb), (unsigned)adn_cdiv(d->N, 256)), dim3(256), 0, st, kp,
+                       pl.mout, pl.rb);
     ADN_CHECK_LAUNCH();
   }
   return ADN_OK;

@@ -103,11 +103,12 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const float* pred, con
 
 template <typename T>
 __global__ __launch_bounds__(256) void final_act_bwd_kernel(const float* gout, const float* out, int64_t n, int kind,
-                                                            T* dz) {
+                                                            int cpad, T* dz) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float o = out[i];
     const float d = kind == 1 ? o * (1.0f - o) : (o > 0.f ? 1.0f : 0.0f);
-    ElemTraits<T>::store(dz + i, gout[i] * d);
+    ElemTraits<T>::store(dz + i * cpad, gout[i] * d);
+    for (int c = 1; c < cpad; ++c) ElemTraits<T>::store(dz + i * cpad + c, 0.0f);
   }
 }
 
@@ -268,18 +269,18 @@ extern "C" int adn_loss_finish(const float* pred, const float* gt, int64_t n, fl
 }
 
 extern "C" int adn_final_act_bwd(const float* gout, const float* out, int64_t n, int32_t final_act, int32_t dtype,
-                                 void* dz, void* stream) {
-  ADN_CHECK_ARG(gout && out && dz && n > 0, "adn_final_act_bwd: bad arguments");
+                                 int32_t c_pad, void* dz, void* stream) {
+  ADN_CHECK_ARG(gout && out && dz && n > 0 && c_pad >= 1, "adn_final_act_bwd: bad arguments");
   ADN_CHECK_ARG(dtype == ADN_F32 || dtype == ADN_BF16, "adn_final_act_bwd: bad dtype %d", dtype);
   int64_t nb = adn_cdiv(n, 256);
   if (nb > 4096) nb = 4096;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == ADN_BF16)
     hipLaunchKernelGGL((final_act_bwd_kernel<uint16_t>), dim3((unsigned)nb), dim3(256), 0, st, gout, out, n, final_act,
-                       reinterpret_cast<uint16_t*>(dz));
+                       c_pad, reinterpret_cast<uint16_t*>(dz));
   else
     hipLaunchKernelGGL((final_act_bwd_kernel<float>), dim3((unsigned)nb), dim3(256), 0, st, gout, out, n, final_act,
-                       reinterpret_cast<float*>(dz));
+                       c_pad, reinterpret_cast<float*>(dz));
   ADN_CHECK_LAUNCH();
   return ADN_OK;
 }

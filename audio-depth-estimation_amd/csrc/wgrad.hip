@@ -22,6 +22,7 @@ struct WParams {
   int tiles_r, tiles_c;
   float* out;     // dW or slab base
   int64_t out_elems;
+  int c_valid;    // gathered channels actually stored (compact [R][16][c_valid]); == C0+C1 normally
 };
 
 __device__ __forceinline__ int swz_f(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
@@ -53,6 +54,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
 
   // plain operand: channel range fixed per thread
   const int r_el = tile_r * 128 + chunk * EPC;
+  const bool r_ok = r_el < p.R0 + p.R1;      // R may be a multiple of 64: upper half tile is zero
   const T* psrc;
   int Rsrc, roff;
   if (r_el < p.R0) {
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
       const int m = s * BKP + prow0 + RPP * k;
       u32x4_t vp = {0u, 0u, 0u, 0u}, vg = {0u, 0u, 0u, 0u};
       if (m < p.Msmall) {
-        vp = *reinterpret_cast<const u32x4_t*>(psrc + (int64_t)m * Rsrc + roff);
+        if (r_ok) vp = *reinterpret_cast<const u32x4_t*>(psrc + (int64_t)m * Rsrc + roff);
         const int b = m / (Hs * Ws);
         const int rem = m - b * (Hs * Ws);
         const int i = rem / Ws;
@@ -208,14 +210,31 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
       for (int r = 0; r < 4; ++r) ct[(wr * 64 + i * 16 + 4 * fg + r) * LDC + wc * 64 + j * 16 + fi] = acc[i][j][r];
   __syncthreads();
   float* out = p.out + (int64_t)split * p.out_elems;
-  const int64_t ldo = (int64_t)16 * C;
   const int cq = tid & 31;    // float4 column group (32 per row)
   const int r0 = tid >> 5;    // 8 rows per pass
+  const int R = p.R0 + p.R1;
+  if (p.c_valid == C) {
+    const int64_t ldo = (int64_t)16 * C;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const int row = r0 + 8 * k;
-    const f32x4_t v = *reinterpret_cast<const f32x4_t*>(ct + row * LDC + cq * 4);
-    *reinterpret_cast<f32x4_t*>(out + (int64_t)(tile_r * 128 + row) * ldo + tile_c * 128 + cq * 4) = v;
+    for (int k = 0; k < 16; ++k) {
+      const int row = r0 + 8 * k;
+      if (tile_r * 128 + row < R) {
+        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(ct + row * LDC + cq * 4);
+        *reinterpret_cast<f32x4_t*>(out + (int64_t)(tile_r * 128 + row) * ldo + tile_c * 128 + cq * 4) = v;
+      }
+    }
+  } else {
+    // zero-padded gathered channels (edge layers): keep only c < c_valid, compact [R][16][c_valid]
+    for (int k = 0; k < 16; ++k) {
+      const int row = r0 + 8 * k;
+      if (tile_r * 128 + row >= R) continue;
+      for (int e = 0; e < 4; ++e) {
+        const int gc = tile_c * 128 + cq * 4 + e;
+        const int tp = gc / C, cc = gc - tp * C;
+        if (cc < p.c_valid)
+          out[((int64_t)(tile_r * 128 + row) * 16 + tp) * p.c_valid + cc] = ct[row * LDC + cq * 4 + e];
+      }
+    }
   }
 }
 
@@ -227,9 +246,11 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(WParams p, int pix_pe
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= p.out_elems) return;
   const int split = blockIdx.y;
-  const int c = (int)(e % C);
-  const int tap = (int)((e / C) % 16);
-  const int r = (int)(e / ((int64_t)16 * C));
+  const int cv = p.c_valid;
+  const int c = (int)(e % cv);
+  const int tap = (int)((e / cv) % 16);
+  const int r = (int)(e / ((int64_t)16 * cv));
+  (void)C;
   const int ky = tap >> 2, kx = tap & 3;
   const T* ps = r < p.R0 ? reinterpret_cast<const T*>(p.plain0) + r : reinterpret_cast<const T*>(p.plain1) + (r - p.R0);
   const int Rs = r < p.R0 ? p.R0 : p.R1;
@@ -268,16 +289,17 @@ struct WPlan {
 void make_wplan(const AdnWgradDesc* d, WPlan* pl) {
   const int R = d->R0 + d->R1, C = d->C0 + d->C1;
   const int64_t msmall = (int64_t)d->B * d->Hs * d->Ws;
-  pl->out_elems = (int64_t)R * 16 * C;
+  const int cv = d->c_valid > 0 ? d->c_valid : C;
+  pl->out_elems = (int64_t)R * 16 * cv;
   const int epc = d->dtype == ADN_BF16 ? 8 : 4;
-  const bool aligned = (R % 128 == 0) && (d->R0 % 128 == 0) && ((16 * C) % 128 == 0) && (C % epc == 0) &&
-                       (d->C0 % epc == 0) && (C >= 64 ? (C % 64 == 0) : (128 % C == 0)) &&
-                       (d->C1 == 0 || d->C0 % 128 == 0);
+  // sources are selected per 16-byte chunk, so a tile may straddle the two plain / gathered sources
+  const bool aligned = (R % 64 == 0) && (d->R0 % epc == 0) && ((16 * C) % 128 == 0) && (C % epc == 0) &&
+                       (d->C0 % epc == 0) && (C >= 128 ? (C % 128 == 0) : (128 % C == 0));
   pl->mfma = aligned;
   if (aligned) {
     const int bkp = d->dtype == ADN_BF16 ? 64 : 32;
     pl->steps = (int)adn_cdiv(msmall, bkp);
-    pl->tiles_r = R / 128;
+    pl->tiles_r = (int)adn_cdiv(R, 128);
     pl->tiles_c = 16 * C / 128;
     const int64_t tiles = (int64_t)pl->tiles_r * pl->tiles_c;
     int ns = (int)adn_cdiv(768, tiles);
@@ -307,6 +329,7 @@ int wvalidate(const AdnWgradDesc* d) {
   ADN_CHECK_ARG(d->plain0 && d->gath0 && d->dw, "adn_wgrad: null operand");
   ADN_CHECK_ARG((d->R1 == 0 || d->plain1) && (d->C1 == 0 || d->gath1), "adn_wgrad: null second source");
   ADN_CHECK_ARG((int64_t)d->B * d->Hs * d->Ws * 4 < (1ll << 31), "adn_wgrad: tensor too large");
+  ADN_CHECK_ARG(d->c_valid >= 0 && d->c_valid <= d->C0 + d->C1, "adn_wgrad: bad c_valid %d", d->c_valid);
   return ADN_OK;
 }
 
@@ -319,6 +342,7 @@ int wrun(const AdnWgradDesc* d, const WPlan& pl, hipStream_t st) {
   p.steps = pl.steps; p.nsplit = pl.nsplit; p.tiles_r = pl.tiles_r; p.tiles_c = pl.tiles_c;
   p.out = pl.nsplit > 1 ? reinterpret_cast<float*>(d->workspace) : d->dw;
   p.out_elems = pl.out_elems;
+  p.c_valid = d->c_valid > 0 ? d->c_valid : d->C0 + d->C1;
   if (pl.mfma) {
     constexpr int BKP = sizeof(T) == 2 ? 64 : 32;
     constexpr int stage = 4 * BKP * 128 * (int)sizeof(T);

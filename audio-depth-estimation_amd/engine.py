@@ -114,11 +114,12 @@ class UNetEngine:
                 w = lv[key].weight
                 X, Y = w.shape[0], w.shape[1]
                 master = self._flat_slice(self.flat_p, w)
-                if T == torch.float32:
+                ypad = lv[key + '_ypad']
+                if T == torch.float32 and ypad == Y:
                     lv[key + '_s2'] = master                       # channels_last memory == S2 operand
                     K.pack_weights(master, X, Y, T, None, lv[key + '_t2'])
                 else:
-                    K.pack_weights(master, X, Y, T, lv[key + '_s2'], lv[key + '_t2'])
+                    K.pack_weights(master, X, Y, T, lv[key + '_s2'], lv[key + '_t2'], y_pad=ypad)
         self.weights_dirty = False
         self._packed_version = self._version_sum()
 
@@ -137,13 +138,27 @@ class UNetEngine:
         dev, T = x.device, self.dtype
         f32 = dict(dtype=torch.float32, device=dev)
         ws_bytes = 16
-        self.x_nhwc = torch.empty(B, H, W, Cin, dtype=T, device=dev)
+        epc = 8 if T == torch.bfloat16 else 4          # elements per 16-byte chunk
+        l0 = self.levels[0]
+        # Edge layers: the first conv (Cin = 2) and the last transposed conv (Cout = 1) run on the MFMA
+        # kernels with their thin channel dimension zero-padded to one 16-byte chunk.
+        self.cin_pad = Cin
+        if l0['down'].weight.shape[0] % 64 == 0 and Cin % epc:
+            self.cin_pad = (Cin + epc - 1) // epc * epc
+        cu_in0, cout0 = l0['up'].weight.shape[0], l0['up'].weight.shape[1]
+        ks = 4 * epc
+        self.n1_path = (cout0 == 1 and cu_in0 % 64 == 0 and (cu_in0 // 2) % ks == 0)
+        self.cout_pad = epc if self.n1_path else cout0
+        self.x_nhwc = torch.empty(B, H, W, self.cin_pad, dtype=T, device=dev)
         for i, lv in enumerate(self.levels):
             dw, uw = lv['down'].weight, lv['up'].weight
             cd_in, cd_out = dw.shape[1], dw.shape[0]
             cu_in, cu_out = uw.shape[0], uw.shape[1]
             hs, wsz = H >> (i + 1), W >> (i + 1)
             lv.update(hs=hs, ws=wsz, cd_in=cd_in, cd_out=cd_out, cu_in=cu_in, cu_out=cu_out)
+            cd_in_p = self.cin_pad if i == 0 else cd_in          # gathered channels as the kernels see them
+            cu_out_p = self.cout_pad if i == 0 else cu_out
+            lv.update(down_ypad=cd_in_p, up_ypad=cu_out_p)
             act = lambda c, h=hs, w_=wsz: torch.empty(B, h, w_, c, dtype=T, device=dev)
             lv['ad'] = act(cd_out) if i < n - 1 else None
             lv['rd'] = act(cd_out)
@@ -156,23 +171,28 @@ class UNetEngine:
                 lv['Gu'] = big(cu_out)
             else:
                 lv['out'] = torch.empty(B, 2 * hs, 2 * wsz, cu_out, **f32)
-                lv['dz0'] = big(cu_out)
+                lv['dz0'] = big(cu_out_p)
             # packed weights
-            if T != torch.float32:
-                lv['down_s2'] = torch.empty(cd_out, 16, cd_in, dtype=T, device=dev)
-                lv['up_s2'] = torch.empty(cu_in, 16, cu_out, dtype=T, device=dev)
+            if T != torch.float32 or cd_in_p != cd_in:
+                lv['down_s2'] = torch.empty(cd_out, 16, cd_in_p, dtype=T, device=dev)
+            if T != torch.float32 or cu_out_p != cu_out:
+                lv['up_s2'] = torch.empty(cu_in, 16, cu_out_p, dtype=T, device=dev)
             lv['down_t2'] = torch.empty(4, cd_in, 4, cd_out, dtype=T, device=dev)
             lv['up_t2'] = torch.empty(4, cu_out, 4, cu_in, dtype=T, device=dev)
             # GEMM plans: partial rows + workspace
             c_up0 = cd_out
             c_up1 = cu_in - cd_out
-            pd, w1 = K.igemm_query(T, GEMM_S2, B, hs, wsz, cd_in, 0, cd_out, [cd_out])            # Li fwd
-            pu, w2 = K.igemm_query(T, GEMM_T2, B, hs, wsz, c_up0, c_up1, cu_out, [cu_out])         # Di fwd
-            pgu, w3 = K.igemm_query(T, GEMM_S2, B, hs, wsz, cu_out, 0, cu_in,                       # Di dgrad
+            pd, w1 = K.igemm_query(T, GEMM_S2, B, hs, wsz, cd_in_p, 0, cd_out, [cd_out])          # Li fwd
+            if i == 0 and self.n1_path:
+                pu, w2 = 0, K.convt_n1_workspace_bytes(B, hs, wsz)                                  # D0 fwd
+            else:
+                pu, w2 = K.igemm_query(T, GEMM_T2, B, hs, wsz, c_up0, c_up1, cu_out, [cu_out])     # Di fwd
+            pgu, w3 = K.igemm_query(T, GEMM_S2, B, hs, wsz, cu_out_p, 0, cu_in,                     # Di dgrad
                                     [c_up0, c_up1] if c_up1 else [c_up0])
-            pgd, w4 = K.igemm_query(T, GEMM_T2, B, hs, wsz, cd_out, 0, cd_in, [cd_in])             # Li dgrad
-            w5 = K.wgrad_workspace_bytes(T, B, hs, wsz, cd_out, 0, cd_in, 0)                       # Li wgrad
-            w6 = K.wgrad_workspace_bytes(T, B, hs, wsz, c_up0, c_up1, cu_out, 0)                   # Di wgrad
+            pgd, w4 = (0, 0) if i == 0 else K.igemm_query(T, GEMM_T2, B, hs, wsz, cd_out, 0, cd_in, [cd_in])  # Li dgrad
+            w5 = K.wgrad_workspace_bytes(T, B, hs, wsz, cd_out, 0, cd_in_p, 0, cd_in if cd_in_p != cd_in else 0)
+            w6 = K.wgrad_workspace_bytes(T, B, hs, wsz, c_up0, c_up1, cu_out_p, 0,
+                                         cu_out if cu_out_p != cu_out else 0)
             ws_bytes = max(ws_bytes, w1, w2, w3, w4, w5, w6)
             lv.update(P_d=pd, P_u=pu, P_gu=pgu, P_gd=pgd)
             for tag, bn, C in (('d', lv['bn_d'], cd_out), ('u', lv['bn_u'], cu_out)):
@@ -213,7 +233,7 @@ class UNetEngine:
             bn = lv['bn_d']
             if bn is None:
                 K.igemm(T, GEMM_S2, B, hs, wsz, src, None, lv['down_s2'], C, EPI_ACT,
-                        [K.Seg(C, out0=lv['ad'], out1=lv['rd'], slope=LEAKY)], ws)
+                        [K.Seg(C, out0=lv['ad'], out1=lv['rd'], slope=LEAKY)], ws, algo_c=lv['cd_in'])
             elif training:
                 K.igemm(T, GEMM_S2, B, hs, wsz, src, None, lv['down_s2'], C, EPI_Z_STATS,
                         [K.Seg(C, out0=lv['zd'], partials=lv['part_d'])], ws)
@@ -234,8 +254,13 @@ class UNetEngine:
             bn = lv['bn_u']
             if i == 0:
                 bias = lv['up'].bias
-                K.igemm(T, GEMM_T2, B, hs, wsz, in0, in1, lv['up_t2'], C, EPI_FINAL,
-                        [K.Seg(C, out0=lv['out'], bias=bias, final_act=1 if self.depth_norm else 0)], ws)
+                fa = 1 if self.depth_norm else 0
+                if self.n1_path:
+                    K.convt_n1_forward(T, B, hs, wsz, in0, in1, self._flat_slice(self.flat_p, lv['up'].weight), bias,
+                                       fa, lv['out'], ws)
+                else:
+                    K.igemm(T, GEMM_T2, B, hs, wsz, in0, in1, lv['up_t2'], C, EPI_FINAL,
+                            [K.Seg(C, out0=lv['out'], bias=bias, final_act=fa)], ws)
             elif training:
                 K.igemm(T, GEMM_T2, B, hs, wsz, in0, in1, lv['up_t2'], C, EPI_Z_STATS,
                         [K.Seg(C, out0=lv['zu'], partials=lv['part_u'])], ws)
@@ -295,14 +320,16 @@ class UNetEngine:
                 dz = lv['Gu']
             in0 = lv['rd']
             in1 = L[i + 1]['ru'] if i < n - 1 else None
-            K.wgrad(T, B, hs, wsz, in0, in1, dz, None, self._flat_slice(self.flat_g, lv['up'].weight), ws)
+            K.wgrad(T, B, hs, wsz, in0, in1, dz, None, self._flat_slice(self.flat_g, lv['up'].weight), ws,
+                    c_valid=lv['cu_out'] if (i == 0 and self.cout_pad != lv['cu_out']) else 0)
             self._ready(lv['up'].weight)
             segs = [K.Seg(lv['cd_out'], out0=lv['Gd'], ref=lv['rd'], slope=0.0)]
             if i < n - 1:
                 nx = L[i + 1]
                 segs.append(K.Seg(nx['cu_out'], out0=nx['Gu'], ref=nx['ru'], slope=0.0, z=nx['zu'],
                                   mean=nx['mean_u'], istd=nx['istd_u'], partials=nx['bpart_u']))
-            K.igemm(T, GEMM_S2, B, hs, wsz, dz, None, lv['up_s2'], lv['cu_in'], EPI_BWD, segs, ws)
+            K.igemm(T, GEMM_S2, B, hs, wsz, dz, None, lv['up_s2'], lv['cu_in'], EPI_BWD, segs, ws,
+                    algo_c=lv['cu_out'])
         # ---- down layers, innermost first
         for i in reversed(range(n)):
             lv = L[i]
@@ -315,7 +342,8 @@ class UNetEngine:
                 K.bn_bwd_apply(lv['Gd'], lv['zd'], B * hs * wsz, C, lv['scale_d'], lv['mean_d'], lv['istd_d'],
                                lv['coef_d'])
             src = self.x_nhwc if i == 0 else L[i - 1]['ad']
-            K.wgrad(T, B, hs, wsz, lv['Gd'], None, src, None, self._flat_slice(self.flat_g, lv['down'].weight), ws)
+            K.wgrad(T, B, hs, wsz, lv['Gd'], None, src, None, self._flat_slice(self.flat_g, lv['down'].weight), ws,
+                    c_valid=lv['cd_in'] if (i == 0 and self.cin_pad != lv['cd_in']) else 0)
             self._ready(lv['down'].weight)
             if i > 0:
                 pv = L[i - 1]

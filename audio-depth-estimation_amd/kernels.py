@@ -16,7 +16,7 @@ from ._lib import (ADN_BF16, ADN_F32, EPI_ACT, EPI_BWD, EPI_FINAL, EPI_RAW, EPI_
 __all__ = ['dtype_code', 'Seg', 'igemm', 'igemm_query', 'wgrad', 'wgrad_workspace_bytes', 'pack_weights',
            'nchw_to_nhwc', 'nhwc_to_nchw', 'bn_fwd_finalize', 'bn_eval_affine', 'bn_act', 'bn_bwd_finalize',
            'bn_bwd_apply', 'loss_stats', 'loss_finish', 'final_act_bwd', 'sum_to_scalar', 'grad_norm',
-           'optimizer_step', 'compute_errors', 'frontend']
+           'optimizer_step', 'compute_errors', 'frontend', 'convt_n1_forward', 'convt_n1_workspace_bytes']
 
 
 def _stream():
@@ -114,16 +114,18 @@ def igemm_query(dtype, geom, B, Hs, Ws, C0, C1, N, seg_channels):
     return p, wsb
 
 
-def igemm(dtype, geom, B, Hs, Ws, in0, in1, w, N, epi, segs, workspace=None):
+def igemm(dtype, geom, B, Hs, Ws, in0, in1, w, N, epi, segs, workspace=None, algo_c=None):
+    """algo_c: real (unpadded) gathered channel count, only used for the algorithmic FLOP count."""
     d = _igemm_desc(dtype, geom, B, Hs, Ws, in0, in1, w, N, epi, segs, workspace)
     ev = _prof_begin()
     _lib.call('adn_igemm', C.byref(d), _stream())
     if ev is not None:     # 2*M_out*N*K, K = taps*Cin  (S2: 16 taps on B*Hs*Ws pixels; T2: 4 taps on 4x the pixels)
-        _prof_end(ev, 'igemm', 2.0 * B * Hs * Ws * N * 16 * (d.C0 + d.C1))
+        _prof_end(ev, 'igemm', 2.0 * B * Hs * Ws * N * 16 * (algo_c if algo_c else d.C0 + d.C1))
 
 
-def _wgrad_desc(dtype, B, Hs, Ws, plain0, plain1, gath0, gath1, dw, workspace):
+def _wgrad_desc(dtype, B, Hs, Ws, plain0, plain1, gath0, gath1, dw, workspace, c_valid=0):
     d = AdnWgradDesc()
+    d.c_valid = c_valid
     d.dtype, d.B, d.Hs, d.Ws = dtype_code(dtype), B, Hs, Ws
     _dev(plain0, plain1, gath0, gath1, dw, workspace)
     d.plain0, d.plain1 = ptr(plain0), ptr(plain1)
@@ -138,8 +140,9 @@ def _wgrad_desc(dtype, B, Hs, Ws, plain0, plain1, gath0, gath1, dw, workspace):
     return d
 
 
-def wgrad_workspace_bytes(dtype, B, Hs, Ws, R0, R1, C0, C1):
+def wgrad_workspace_bytes(dtype, B, Hs, Ws, R0, R1, C0, C1, c_valid=0):
     d = AdnWgradDesc()
+    d.c_valid = c_valid
     d.dtype, d.B, d.Hs, d.Ws, d.R0, d.R1, d.C0, d.C1 = dtype_code(dtype), B, Hs, Ws, R0, R1, C0, C1
     d.plain0 = d.gath0 = d.dw = 1
     d.plain1 = 1 if R1 else None
@@ -151,23 +154,26 @@ def wgrad_workspace_bytes(dtype, B, Hs, Ws, R0, R1, C0, C1):
     return n
 
 
-def wgrad(dtype, B, Hs, Ws, plain0, plain1, gath0, gath1, dw, workspace=None):
-    d = _wgrad_desc(dtype, B, Hs, Ws, plain0, plain1, gath0, gath1, dw, workspace)
+def wgrad(dtype, B, Hs, Ws, plain0, plain1, gath0, gath1, dw, workspace=None, c_valid=0):
+    d = _wgrad_desc(dtype, B, Hs, Ws, plain0, plain1, gath0, gath1, dw, workspace, c_valid)
     ev = _prof_begin()
     _lib.call('adn_wgrad', C.byref(d), _stream())
     if ev is not None:
-        _prof_end(ev, 'wgrad', 2.0 * B * Hs * Ws * (d.R0 + d.R1) * 16 * (d.C0 + d.C1))
+        _prof_end(ev, 'wgrad', 2.0 * B * Hs * Ws * (d.R0 + d.R1) * 16 * (c_valid if c_valid else d.C0 + d.C1))
 
 
-def pack_weights(master, X, Y, dtype, s2_out=None, t2_out=None):
+def pack_weights(master, X, Y, dtype, s2_out=None, t2_out=None, y_pad=None):
+    """master f32 [X][16][Y] -> s2 [X][16][y_pad] (zero padded) and/or t2 [4][Y][4][X]."""
     _dev(master, s2_out, t2_out)
-    _lib.call('adn_pack_weights', ptr(master), X, Y, dtype_code(dtype), ptr(s2_out), ptr(t2_out), _stream())
+    _lib.call('adn_pack_weights', ptr(master), X, Y, Y if y_pad is None else y_pad, dtype_code(dtype), ptr(s2_out),
+              ptr(t2_out), _stream())
 
 
 def nchw_to_nhwc(src, dst):
+    """src f32 [B,C,H,W] -> dst [B,H,W,Cpad] (Cpad = dst.shape[-1] >= C, extra channels zero)."""
     B, Cc, H, W = src.shape
     _dev(src, dst)
-    _lib.call('adn_nchw_to_nhwc', ptr(src), ptr(dst), B, Cc, H, W, dtype_code(dst.dtype), _stream())
+    _lib.call('adn_nchw_to_nhwc', ptr(src), ptr(dst), B, Cc, dst.shape[-1], H, W, dtype_code(dst.dtype), _stream())
 
 
 def nhwc_to_nchw(src, dst):
@@ -221,9 +227,25 @@ def loss_finish(pred, gt, scale, mask_mode, eps, stats, criterion, l1_weight, si
 
 
 def final_act_bwd(gout, out, final_act, dz):
+    """dz [pixels, Cpad]: channel 0 = gout * act'(out), padded channels zero."""
     _dev(gout, out, dz)
-    _lib.call('adn_final_act_bwd', ptr(gout), ptr(out), out.numel(), final_act, dtype_code(dz.dtype), ptr(dz),
-              _stream())
+    _lib.call('adn_final_act_bwd', ptr(gout), ptr(out), out.numel(), final_act, dtype_code(dz.dtype),
+              dz.numel() // out.numel(), ptr(dz), _stream())
+
+
+def convt_n1_workspace_bytes(B, Hs, Ws):
+    return _lib.load().adn_convt_n1_workspace_bytes(B, Hs, Ws)
+
+
+def convt_n1_forward(dtype, B, Hs, Ws, in0, in1, w_master, bias, final_act, out, workspace):
+    _dev(in0, in1, w_master, bias, out, workspace)
+    ev = _prof_begin()
+    _lib.call('adn_convt_n1_forward', dtype_code(dtype), B, Hs, Ws, ptr(in0), in0.shape[-1], ptr(in1),
+              in1.shape[-1] if in1 is not None else 0, ptr(w_master), ptr(bias), final_act, ptr(out), ptr(workspace),
+              workspace.numel() * workspace.element_size(), _stream())
+    if ev is not None:
+        cin = in0.shape[-1] + (in1.shape[-1] if in1 is not None else 0)
+        _prof_end(ev, 'convt_n1', 2.0 * B * Hs * Ws * 16 * cin)
 
 
 def sum_to_scalar(x, out, workspace):

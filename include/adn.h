@@ -110,23 +110,25 @@ typedef struct {
   int32_t B, Hs, Ws;          /* small grid */
   const void* plain0; const void* plain1; int32_t R0, R1;
   const void* gath0;  const void* gath1;  int32_t C0, C1;
-  float* dw;                  /* [R0+R1][16][C0+C1] f32 */
+  float* dw;                  /* [R0+R1][16][c_valid] f32 */
   void* workspace; int64_t workspace_bytes;
+  int32_t c_valid;            /* 0 = all gathered channels; else only c < c_valid are stored (the edge
+                                 layers run with their 2 / 1 real channels zero-padded to one 16-byte chunk) */
 } AdnWgradDesc;
 int64_t adn_wgrad_workspace_bytes(const AdnWgradDesc* d);
 int adn_wgrad(const AdnWgradDesc* d, void* stream);
 
 /* Cast/pack master f32 weights ([X][4][4][Y] memory order = torch channels_last of an
  * [X,Y,4,4] parameter) into the two GEMM operand forms.
- *   s2_out: [X][16][Y] in dtype (plain cast)            or NULL
- *   t2_out: [4][Y][4][X] in dtype (phase split)         or NULL */
-int adn_pack_weights(const float* master, int32_t X, int32_t Y, int32_t dtype, void* s2_out,
-                     void* t2_out, void* stream);
+ *   s2_out: [X][16][y_pad] in dtype (cast; channels Y..y_pad-1 zero)   or NULL
+ *   t2_out: [4][Y][4][X] in dtype (phase split)                        or NULL */
+int adn_pack_weights(const float* master, int32_t X, int32_t Y, int32_t y_pad, int32_t dtype,
+                     void* s2_out, void* t2_out, void* stream);
 
 /* NCHW f32 <-> NHWC dtype layout conversion of the network input/output
- * (model(audio) boundary, train.py:642). */
-int adn_nchw_to_nhwc(const float* src, void* dst, int32_t B, int32_t C, int32_t H, int32_t W,
-                     int32_t dtype, void* stream);
+ * (model(audio) boundary, train.py:642).  dst has c_pad >= C channels, the extra ones zero. */
+int adn_nchw_to_nhwc(const float* src, void* dst, int32_t B, int32_t C, int32_t c_pad, int32_t H,
+                     int32_t W, int32_t dtype, void* stream);
 int adn_nhwc_to_nchw(const void* src, float* dst, int32_t B, int32_t C, int32_t H, int32_t W,
                      int32_t dtype, void* stream);
 
@@ -167,9 +169,19 @@ int adn_loss_finish(const float* pred, const float* gt, int64_t n, float scale, 
                     float silog_weight, float silog_lambda, float* loss_out, float* grad,
                     void* stream);
 /* Derivative of the generator's last activation (ReLU or Sigmoid, unetbaseline_model.py:201-206):
- * dz (dtype, [pixels] single channel NHWC) = gout * act'(out); also dbias partial sums. */
+ * dz (dtype, [pixels][c_pad], channel 0 = gout * act'(out), other channels zero). */
 int adn_final_act_bwd(const float* gout, const float* out, int64_t n, int32_t final_act,
-                      int32_t dtype, void* dz, void* stream);
+                      int32_t dtype, int32_t c_pad, void* dz, void* stream);
+
+/* Outermost ConvTranspose2d(k4,s2,p1) with ONE output channel + bias + ReLU/Sigmoid
+ * (unetbaseline_model.py:196-206), as a pointwise GEMM P[m][16 taps] = in[m][:] . W[:][tap] on the
+ * small grid followed by a 4-tap gather per output pixel (col2im).  w = f32 master [C0+C1][16].
+ * out: f32 [B][2Hs][2Ws].  Workspace holds P (f32 [B*Hs*Ws][16]). */
+int64_t adn_convt_n1_workspace_bytes(int32_t B, int32_t Hs, int32_t Ws);
+int adn_convt_n1_forward(int32_t dtype, int32_t B, int32_t Hs, int32_t Ws, const void* in0, int32_t C0,
+                         const void* in1, int32_t C1, const float* w, const float* bias,
+                         int32_t final_act, float* out, void* workspace, int64_t workspace_bytes,
+                         void* stream);
 /* sum over n f32/dtype elements into one f32 (bias gradient of the outermost ConvTranspose2d). */
 int adn_sum_to_scalar(const void* x, int64_t n, int32_t dtype, float* out, void* workspace,
                       int64_t workspace_bytes, void* stream);
