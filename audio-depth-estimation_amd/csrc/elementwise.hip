@@ -13,29 +13,41 @@ inline unsigned blocks_for(int64_t n, int per_block = 256) {
   return (unsigned)b;
 }
 
-// master [X][4][4][Y] f32 -> s2 [X][16][Ypad] (cast, zero padded channels), t2 [4][Y][4][X] (phase split)
+// master [X][4][4][Y] f32 -> s2 [X][16][Ypad] (cast, zero padded channels): coalesced both sides
 template <typename T>
-__global__ __launch_bounds__(256) void pack_weights_kernel(const float* master, int X, int Y, int Ypad, T* s2,
-                                                           T* t2) {
-  const int64_t n = (int64_t)X * 16 * Y;
-  if (s2) {
-    const int64_t np = (int64_t)X * 16 * Ypad;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < np; e += (int64_t)gridDim.x * 256) {
-      const int y = (int)(e % Ypad);
-      const int64_t xt = e / Ypad;
-      ElemTraits<T>::store(s2 + e, y < Y ? master[xt * Y + y] : 0.0f);
-    }
+__global__ __launch_bounds__(256) void pack_s2_kernel(const float* master, int X, int Y, int Ypad, T* s2) {
+  const int64_t np = (int64_t)X * 16 * Ypad;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < np; e += (int64_t)gridDim.x * 256) {
+    const int y = (int)(e % Ypad);
+    const int64_t xt = e / Ypad;
+    ElemTraits<T>::store(s2 + e, y < Y ? master[xt * Y + y] : 0.0f);
   }
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
-    if (t2) {
-      // destination-ordered: e -> (phase, y, t, x)
-      const int x = (int)(e % X);
-      const int t = (int)((e / X) % 4);
-      const int y = (int)((e / ((int64_t)4 * X)) % Y);
-      const int phase = (int)(e / ((int64_t)4 * X * Y));
-      const int kh = adn_t2_kh(phase >> 1, t >> 1), kw = adn_t2_kh(phase & 1, t & 1);
-      ElemTraits<T>::store(t2 + e, master[(((int64_t)x * 4 + kh) * 4 + kw) * Y + y]);
-    }
+}
+
+// master [X][16 taps][Y] f32 -> t2 [4 phases][Y][4 taps][X]: a per-tap [X][Y] -> [Y][X] transpose through
+// a 32x33 LDS tile so that both the reads (y fastest) and the writes (x fastest) are coalesced.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_t2_kernel(const float* master, int X, int Y, T* t2) {
+  __shared__ float tile[32][33];
+  const int tap = blockIdx.y;                       // kh*4 + kw
+  const int kh = tap >> 2, kw = tap & 3;
+  // inverse of adn_t2_kh: kh=1 -> (ph 0, t 0), kh=3 -> (0,1), kh=0 -> (1,0), kh=2 -> (1,1)
+  const int ph = (kh & 1) ? 0 : 1, ty = (kh == 3 || kh == 2) ? 1 : 0;
+  const int pw = (kw & 1) ? 0 : 1, tx = (kw == 3 || kw == 2) ? 1 : 0;
+  const int phase = ph * 2 + pw, t = ty * 2 + tx;
+  const int tiles_y = (Y + 31) / 32;
+  const int x0 = (blockIdx.x / tiles_y) * 32, y0 = (blockIdx.x % tiles_y) * 32;
+  const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int x = x0 + ly + 8 * r, y = y0 + lx;
+    tile[ly + 8 * r][lx] = (x < X && y < Y) ? master[((int64_t)x * 16 + tap) * Y + y] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int y = y0 + ly + 8 * r, x = x0 + lx;
+    if (x < X && y < Y) ElemTraits<T>::store(t2 + (((int64_t)phase * Y + y) * 4 + t) * X + x, tile[lx][ly + 8 * r]);
   }
 }
 
@@ -201,13 +213,25 @@ extern "C" int adn_pack_weights(const float* master, int32_t X, int32_t Y, int32
   ADN_CHECK_ARG(s2_out || t2_out, "adn_pack_weights: no output");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int64_t n = (int64_t)X * 16 * y_pad;
-  if (dtype == ADN_BF16)
-    hipLaunchKernelGGL((pack_weights_kernel<uint16_t>), dim3(blocks_for(n)), dim3(256), 0, st, master, X, Y, y_pad,
-                       reinterpret_cast<uint16_t*>(s2_out), reinterpret_cast<uint16_t*>(t2_out));
-  else
-    hipLaunchKernelGGL((pack_weights_kernel<float>), dim3(blocks_for(n)), dim3(256), 0, st, master, X, Y, y_pad,
-                       reinterpret_cast<float*>(s2_out), reinterpret_cast<float*>(t2_out));
-  ADN_CHECK_LAUNCH();
+  if (s2_out) {
+    if (dtype == ADN_BF16)
+      hipLaunchKernelGGL((pack_s2_kernel<uint16_t>), dim3(blocks_for(n)), dim3(256), 0, st, master, X, Y, y_pad,
+                         reinterpret_cast<uint16_t*>(s2_out));
+    else
+      hipLaunchKernelGGL((pack_s2_kernel<float>), dim3(blocks_for(n)), dim3(256), 0, st, master, X, Y, y_pad,
+                         reinterpret_cast<float*>(s2_out));
+    ADN_CHECK_LAUNCH();
+  }
+  if (t2_out) {
+    const dim3 grid((unsigned)(adn_cdiv(X, 32) * adn_cdiv(Y, 32)), 16);
+    if (dtype == ADN_BF16)
+      hipLaunchKernelGGL((pack_t2_kernel<uint16_t>), grid, dim3(256), 0, st, master, X, Y,
+                         reinterpret_cast<uint16_t*>(t2_out));
+    else
+      hipLaunchKernelGGL((pack_t2_kernel<float>), grid, dim3(256), 0, st, master, X, Y,
+                         reinterpret_cast<float*>(t2_out));
+    ADN_CHECK_LAUNCH();
+  }
   return ADN_OK;
 }
 

@@ -302,7 +302,7 @@ void make_wplan(const AdnWgradDesc* d, WPlan* pl) {
     pl->tiles_r = (int)adn_cdiv(R, 128);
     pl->tiles_c = 16 * C / 128;
     const int64_t tiles = (int64_t)pl->tiles_r * pl->tiles_c;
-    int ns = (int)adn_cdiv(768, tiles);
+    int ns = (int)adn_cdiv(512, tiles);
     const int max_by_steps = pl->steps / 4 > 0 ? pl->steps / 4 : 1;
     if (ns > max_by_steps) ns = max_by_steps;
     if (ns > 256) ns = 256;

@@ -409,6 +409,19 @@ class FusedTrainer:
         self.mask_mode = 0 if mask_mode == 'ne0' else 1
         self.ddp = ddp
         self._ready = False
+        self._graph = None
+        self._graph_after = None
+        self._calls = 0
+
+    def enable_graph(self, after_steps=3):
+        """Capture the whole step into one hipGraph after ``after_steps`` eager steps (fixed batch shape).
+
+        Every launch of the step is on the current stream and nothing synchronises with the host, so the
+        ~140 kernel launches replay as one graph launch.  Not combined with the data-parallel reducer.
+        """
+        if self.ddp is not None:
+            raise RuntimeError('graph capture of the step is only wired for single-process training')
+        self._graph_after = after_steps
 
     def _setup(self, dev):
         eng = self.engine
@@ -429,6 +442,23 @@ class FusedTrainer:
         self._ready = True
 
     def step(self, audio, gt):
+        self._calls += 1
+        if self._graph is not None:
+            self._g_audio.copy_(audio)
+            self._g_gt.copy_(gt)
+            self._graph.replay()
+            return self._g_out
+        if self._graph_after is not None and self._calls > self._graph_after and self._ready:
+            self._g_audio, self._g_gt = audio.clone(), gt.contiguous().float().clone()
+            torch.cuda.synchronize()
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._g_out = self._step_impl(self._g_audio, self._g_gt)
+            self._graph.replay()            # capture only records: run the step once for real
+            return self._g_out
+        return self._step_impl(audio, gt)
+
+    def _step_impl(self, audio, gt):
         eng = self.engine
         if not self._ready or self._flat_id != (eng.flat_p.data_ptr() if eng.flat_p is not None else None):
             self._setup(audio.device)
