@@ -5,13 +5,15 @@
 //        written to the large-grid pixel (2i+ph, 2j+pw)
 //
 // MFMA path: 128 x BN output tile per 256-thread workgroup (4 waves as 2x2, each 64 x BN/2),
-// K-step = 128 bytes of channels of one tap (64 bf16 / 32 f32); operands staged through LDS with
-// an XOR swizzle (16-byte chunk ^= (row>>1)&7) so that the ds_read_b128 fragment reads and the
-// ds_write_b128 staging writes are bank-conflict free; register-staged double buffering (global
-// loads of step s+1 are in flight while step s runs on the matrix cores).  Small-M layers use
+// K-step = 128 bytes of K (64 bf16 / 32 f32); both operands go global -> LDS by LDS-DMA
+// (buffer_load_dwordx4 ... lds: no VGPR staging, no ds_write, zero padding by the hardware range check),
+// 2- or 3-stage ring: the DMA of the next step(s) is in flight while step s runs on the matrix cores.  LDS image is XOR swizzled (16-byte chunk ^= (row>>1)&7,
+// applied on the per-lane SOURCE address since the DMA destination is lane-linear) so that the
+// ds_read_b128 fragment reads are bank-conflict free.  Small-M layers use
 // split-K into f32 slabs + a reduce pass.  The epilogue goes through LDS so that every global
 // access of the epilogue is a 16-byte, row-contiguous access.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "epilogue.h"
 
@@ -32,7 +34,6 @@ struct KParams {
   float* slab;    // split-K / generic scratch
 };
 
-constexpr int BM = 128;
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   // bijective XCD-contiguous remap (cdna_hip_programming.md T1): blocks b and b+8 share an XCD.
@@ -40,22 +41,36 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
-template <typename T, int BN, int GEOM>
-__global__ __launch_bounds__(256, 2) void igemm_mfma_kernel(KParams p) {
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// BM = 128: 4 waves (2x2), 2 LDS stages, 2 workgroups per CU  (small-M / split-K layers)
+// BM = 256: 8 waves (4x2), 3 LDS stages, 1 workgroup per CU: the DMA of steps s+1 and s+2 stays in
+//           flight across the per-step barrier (counted s_waitcnt vmcnt, raw s_barrier).
+template <typename T, int BM, int BN, int GEOM, bool WIDE>
+__global__ __launch_bounds__(BM * 2, 2) void igemm_mfma_kernel(KParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins exist only in the device pass; the host needs the stub only
+  constexpr int NTHR = BM * 2;              // 64 threads per 64x(BN/2) wave tile, 2 wave columns
+  constexpr int NW = NTHR / 64;
+  constexpr int STAGES = BM == 256 ? 3 : 2;
   constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
   constexpr int BK = 8 * EPC;               // elements per K-step (128 bytes)
   constexpr int WN = BN / 2;                // wave tile columns
   constexpr int NT = WN / 16;
   constexpr int MT = 4;
-  constexpr int BROWS = BN / 32;            // B rows per thread
+  constexpr int RPASS = NTHR / 8;           // tile rows filled per loader pass (8 rows per wave-instruction)
+  constexpr int APASS = BM / RPASS;         // = 4
+  constexpr int BPASS = BN / RPASS;
+  constexpr int LOADS = APASS + BPASS;      // LDS-DMA instructions per wave per stage
+  constexpr int STAGE_BYTES = (BM + BN) * 128;
   constexpr int LDC = BN + 4;               // epilogue tile leading dimension (floats)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* As = smem;                       // [2][BM][128 B]
-  char* Bs = smem + 2 * BM * 128;        // [2][BN][128 B]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int nwg = p.tiles_m * p.tiles_n;
   const int wg = xcd_remap(blockIdx.x, nwg);
@@ -69,89 +84,125 @@ __global__ __launch_bounds__(256, 2) void igemm_mfma_kernel(KParams p) {
   const int Hl = 2 * Hs, Wl = 2 * Ws;
   const int Cin = p.C0 + p.C1;
 
-  // ---- loader geometry ----
-  const int chunk = tid & 7;
-  const int lrow = tid >> 3;  // 0..31
-  int a_b[4], a_y[4], a_x[4];
-  bool a_ok[4];
+  // ---- loader geometry (LDS-DMA: buffer_load_dwordx4 ... lds writes wave-uniform base + lane*16) ----
+  // Wave w fills rows j*RPASS + w*8 .. +8 of each tile with ONE 1-KiB wave-instruction: lane l lands on row
+  // (l>>3), physical 16-byte chunk (l&7).  The XOR swizzle therefore goes on the SOURCE side: the lane
+  // fetches logical chunk pc ^ ((row>>1)&7) (same for all j because RPASS rows keep (row>>1)&7).
+  //
+  // Addressing is split so that the K loop costs (almost) no vector instructions (the first version
+  // spent 4.5 VALU per MFMA on 64-bit address arithmetic and was issue bound at ~25 % MFMA utilisation):
+  //   address = descriptor base (SGPRs, shifted back by one row + one pixel so tap offsets are >= 0)
+  //           + voffset (per lane, CONSTANT over the K loop: pixel (2y,2x) resp. (y,x) of the row + chunk)
+  //           + soffset (scalar per K-step: tap shift + channel offset)
+  // Padding taps and rows beyond M use voffset = 0x80000000: the hardware range check fails and the DMA
+  // writes zeros into LDS (verified on gfx950), so zero padding needs no memory at all.
+  constexpr unsigned OOB = 0x80000000u;
+  constexpr int ESZ = (int)sizeof(T);
+  const int pc = tid & 7;
+  const int lrow = tid >> 3;
+  const int lc = pc ^ ((lrow >> 1) & 7);
+  const int Wg = (GEOM == ADN_GEMM_S2) ? Wl : Ws;
+  const int ktot = (GEOM == ADN_GEMM_S2 ? 16 : 4) * Cin;
+  const int ntaps = GEOM == ADN_GEMM_S2 ? 16 : 4;
+
+  unsigned roff0[APASS], roff1[APASS], amask[APASS];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int m = tile_m * BM + lrow + 32 * j;
-    a_ok[j] = m < p.Msmall;
-    const int mm = a_ok[j] ? m : 0;
+  for (int j = 0; j < APASS; ++j) {
+    const int m = tile_m * BM + lrow + RPASS * j;
+    const bool okm = m < p.Msmall;
+    const int mm = okm ? m : 0;
     const int b = mm / (Hs * Ws);
     const int rem = mm - b * (Hs * Ws);
-    const int i = rem / Ws;
-    a_b[j] = b;
-    a_y[j] = i;
-    a_x[j] = rem - i * Ws;
+    const int y = rem / Ws;
+    const int x = rem - y * Ws;
+    unsigned mask = 0;
+    int pix;
+    if constexpr (GEOM == ADN_GEMM_S2) {
+      pix = (b * Hl + 2 * y) * Wl + 2 * x;                   // tap (ky,kx) adds (ky-1)*Wl + (kx-1)
+      for (int t = 0; t < 16; ++t) {
+        const int iy = 2 * y - 1 + (t >> 2), ix = 2 * x - 1 + (t & 3);
+        if ((unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl) mask |= 1u << t;
+      }
+    } else {
+      pix = (b * Hs + y) * Ws + x;                            // tap (ty,tx) adds dy*Ws + dx
+      for (int t = 0; t < 4; ++t) {
+        const int iy = y + adn_t2_dy(ph, t >> 1), ix = x + adn_t2_dy(pw, t & 1);
+        if ((unsigned)iy < (unsigned)Hs && (unsigned)ix < (unsigned)Ws) mask |= 1u << t;
+      }
+    }
+    amask[j] = okm ? mask : 0u;
+    roff0[j] = (unsigned)pix * (unsigned)(p.C0 * ESZ);
+    roff1[j] = (unsigned)pix * (unsigned)(p.C1 * ESZ);
   }
+  unsigned boff[BPASS > 0 ? BPASS : 1];
+#pragma unroll
+  for (int j = 0; j < BPASS; ++j) boff[j] = (unsigned)((tile_n * BN + lrow + RPASS * j) * ktot + lc * EPC) * ESZ;
 
   const int s_begin = (int)(((int64_t)p.ksteps * split) / p.nsplit);
   const int s_end = (int)(((int64_t)p.ksteps * (split + 1)) / p.nsplit);
 
-  u32x4_t ra[4], rb[BROWS];
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(reinterpret_cast<const char*>(p.in0) - (int64_t)(Wg + 1) * p.C0 * ESZ), 0, 0x7ffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(reinterpret_cast<const char*>(p.C1 ? p.in1 : p.in0) - (int64_t)(Wg + 1) * p.C1 * ESZ), 0, 0x7ffffff0,
+      0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(reinterpret_cast<const char*>(p.w) + (GEOM == ADN_GEMM_T2 ? (int64_t)phase * p.N * ktot * ESZ : 0)), 0,
+      0x7ffffff0, 0x00020000);
 
-  // K is laid out [tap][channel] contiguously, so this thread's 16-byte chunk of K-step s starts at
-  // k0 = s*BK + chunk*EPC; tap and channel follow per thread, which also covers narrow layers
-  // (Cin = 8, 16, 32: several taps inside one K-step) and the two-source virtual concat.
-  const int ktot = (GEOM == ADN_GEMM_S2 ? 16 : 4) * Cin;
-  auto load_step = [&](int s) {
-    const int k0 = s * BK + chunk * EPC;
-    const int tap = k0 / Cin;
-    const int c = k0 - tap * Cin;
-    const T* src;
-    int Csrc, coff;
-    if (c < p.C0) {
-      src = reinterpret_cast<const T*>(p.in0);
-      Csrc = p.C0;
-      coff = c;
+  // scalar K-loop state of the NEXT step to issue: tap index and channel offset inside the tap
+  const int kpt = WIDE ? Cin / BK : 1;
+  int is_tap = WIDE ? s_begin / kpt : 0;
+  int is_c0 = WIDE ? (s_begin - is_tap * kpt) * BK : 0;
+
+  auto issue_step = [&](int s, int buf) {
+    char* adst = smem + buf * STAGE_BYTES + wave * 1024;
+    char* bdst = adst + BM * 128;
+    if constexpr (WIDE) {
+      // whole K-step inside one tap and one source: everything but the validity bit is scalar
+      const int tap = is_tap, c0 = is_c0;
+      const bool second = c0 >= p.C0;
+      const int Cs = second ? p.C1 : p.C0;
+      const int coff = second ? c0 - p.C0 : c0;
+      int shift;
+      if constexpr (GEOM == ADN_GEMM_S2) shift = (tap >> 2) * Wl + (tap & 3);
+      else shift = (adn_t2_dy(ph, tap >> 1) + 1) * Ws + (adn_t2_dy(pw, tap & 1) + 1);
+      const int soff = (shift * Cs + coff) * ESZ + lc * 0;
+      const unsigned lane_c = (unsigned)(lc * EPC * ESZ);
+#pragma unroll
+      for (int j = 0; j < APASS; ++j) {
+        const unsigned base = (second ? roff1[j] : roff0[j]) + lane_c;
+        const unsigned voff = ((amask[j] >> tap) & 1u) ? base : OOB;
+        if (second)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lptr_t)(adst + j * (RPASS * 128)), 16, voff, soff, 0, 0);
+        else
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lptr_t)(adst + j * (RPASS * 128)), 16, voff, soff, 0, 0);
+      }
+      is_c0 += BK;
+      if (is_c0 == Cin) {
+        is_c0 = 0;
+        ++is_tap;
+      }
     } else {
-      src = reinterpret_cast<const T*>(p.in1);
-      Csrc = p.C1;
-      coff = c - p.C0;
-    }
+      // narrow layers (Cin = 8, 16, 32; single source): several taps inside one K-step, per-lane tap
+      const int k0 = s * BK + lc * EPC;
+      const int tap = k0 / Cin;
+      const int c = k0 - tap * Cin;
+      int shift;
+      if constexpr (GEOM == ADN_GEMM_S2) shift = (tap >> 2) * Wl + (tap & 3);
+      else shift = (adn_t2_dy(ph, tap >> 1) + 1) * Ws + (adn_t2_dy(pw, tap & 1) + 1);
+      const unsigned lane_off = (unsigned)((shift * Cin + c) * ESZ);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int iy, ix, H, W;
-      if constexpr (GEOM == ADN_GEMM_S2) {
-        iy = 2 * a_y[j] - 1 + (tap >> 2);
-        ix = 2 * a_x[j] - 1 + (tap & 3);
-        H = Hl;
-        W = Wl;
-      } else {
-        iy = a_y[j] + adn_t2_dy(ph, tap >> 1);
-        ix = a_x[j] + adn_t2_dy(pw, tap & 1);
-        H = Hs;
-        W = Ws;
+      for (int j = 0; j < APASS; ++j) {
+        const unsigned voff = (tap < ntaps && ((amask[j] >> tap) & 1u)) ? roff0[j] + lane_off : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lptr_t)(adst + j * (RPASS * 128)), 16, voff, 0, 0, 0);
       }
-      const bool ok = a_ok[j] && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-      u32x4_t v = {0u, 0u, 0u, 0u};
-      if (ok) {
-        const int64_t pix = ((int64_t)a_b[j] * H + iy) * W + ix;
-        v = *reinterpret_cast<const u32x4_t*>(src + pix * Csrc + coff);
-      }
-      ra[j] = v;
     }
-    const T* w = reinterpret_cast<const T*>(p.w);
+    const int soffb = s * 128;
 #pragma unroll
-    for (int j = 0; j < BROWS; ++j) {
-      const int n = tile_n * BN + lrow + 32 * j;
-      const int64_t row = (GEOM == ADN_GEMM_S2) ? (int64_t)n : ((int64_t)phase * p.N + n);
-      rb[j] = *reinterpret_cast<const u32x4_t*>(w + row * ktot + k0);
-    }
-  };
-  auto store_step = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = lrow + 32 * j;
-      *reinterpret_cast<u32x4_t*>(As + buf * (BM * 128) + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)) = ra[j];
-    }
-#pragma unroll
-    for (int j = 0; j < BROWS; ++j) {
-      const int row = lrow + 32 * j;
-      *reinterpret_cast<u32x4_t*>(Bs + buf * (BN * 128) + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)) = rb[j];
-    }
+    for (int j = 0; j < BPASS; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lptr_t)(bdst + j * (RPASS * 128)), 16, boff[j], soffb, 0, 0);
   };
 
   f32x4_t acc[MT][NT];
@@ -160,20 +211,30 @@ __global__ __launch_bounds__(256, 2) void igemm_mfma_kernel(KParams p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  if (s_begin < s_end) {
-    load_step(s_begin);
-    store_step(0);
-  }
-  __syncthreads();
+  // ---- pipeline: STAGES-1 steps of LDS-DMA in flight; one raw barrier per K-step ----
+  // At the top of step s the stages s .. s+STAGES-2 have been issued.  "s_waitcnt vmcnt(LOADS*(STAGES-2))"
+  // retires this wave's DMA of stage s (vmcnt counts in issue order), the barrier then (a) makes every
+  // wave's part of stage s visible and (b) proves that all waves finished reading stage s-1, whose buffer
+  // the DMA of stage s+STAGES-1 may now overwrite.
+#pragma unroll
+  for (int d = 0; d < STAGES - 1; ++d)
+    if (s_begin + d < s_end) issue_step(s_begin + d, d);
 
   const int frow = lane & 15;
   const int fq = lane >> 4;
+  int cur = 0;
   for (int s = s_begin; s < s_end; ++s) {
-    const int cur = (s - s_begin) & 1;
-    const bool more = (s + 1) < s_end;
-    if (more) load_step(s + 1);
-    const char* Ab = As + cur * (BM * 128);
-    const char* Bb = Bs + cur * (BN * 128);
+    if (STAGES == 3 && s + 1 < s_end) wait_vmcnt<LOADS>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    {
+      int nb = cur + STAGES - 1;
+      if (nb >= STAGES) nb -= STAGES;
+      if (s + STAGES - 1 < s_end) issue_step(s + STAGES - 1, nb);
+    }
+    const char* Ab = smem + cur * STAGE_BYTES;
+    const char* Bb = Ab + BM * 128;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       u32x4_t af[MT], bf[NT];
@@ -192,9 +253,9 @@ __global__ __launch_bounds__(256, 2) void igemm_mfma_kernel(KParams p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) mma_tile<T>(af[i], bf[j], acc[i][j]);
     }
-    if (more) store_step(cur ^ 1);
-    __syncthreads();
+    cur = cur + 1 == STAGES ? 0 : cur + 1;
   }
+  __syncthreads();   // all waves done with the staging buffers before the epilogue tile reuses them
 
   // ---- epilogue through LDS: ctile[BM][LDC] f32 ----
   float* ct = reinterpret_cast<float*>(smem);
@@ -208,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void igemm_mfma_kernel(KParams p) {
   __syncthreads();
 
   constexpr int CPR = BN / 8;        // 8-channel column groups per row
-  constexpr int RSTEP = 256 / CPR;   // rows covered per pass
+  constexpr int RSTEP = NTHR / CPR;  // rows covered per pass
   constexpr int RPT = BM / RSTEP;    // rows per thread
   const int cg = tid % CPR;
   const int rsub = tid / CPR;
@@ -266,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void igemm_mfma_kernel(KParams p) {
   }
 
   if (sg.partials != nullptr && (epi == ADN_EPI_Z_STATS || epi == ADN_EPI_BWD)) {
-    // reduce over the row subsets: lanes sharing cg inside a wave, then the 4 waves through LDS.
+    // reduce over the row subsets: lanes sharing cg inside a wave, then the NW waves through LDS.
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
 #pragma unroll
@@ -276,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void igemm_mfma_kernel(KParams p) {
       }
     }
     __syncthreads();  // everyone is done reading ctile
-    float* red = reinterpret_cast<float*>(smem);  // [4 waves][2][BN]
+    float* red = reinterpret_cast<float*>(smem);  // [NW waves][2][BN]
     if (lane < CPR) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -287,8 +348,9 @@ __global__ __launch_bounds__(256, 2) void igemm_mfma_kernel(KParams p) {
     __syncthreads();
     if (tid < 2 * BN) {
       const int st = tid / BN, c = tid % BN;
-      const float t = red[(0 * 2 + st) * BN + c] + red[(1 * 2 + st) * BN + c] + red[(2 * 2 + st) * BN + c] +
-                      red[(3 * 2 + st) * BN + c];
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += red[(w * 2 + st) * BN + c];
       const int n = tile_n * BN + c;
       const AdnEpiSeg& sq = (n < p.seg[0].channels) ? p.seg[0] : p.seg[1];
       const int ncl = (n < p.seg[0].channels) ? n : n - p.seg[0].channels;
@@ -296,6 +358,7 @@ __global__ __launch_bounds__(256, 2) void igemm_mfma_kernel(KParams p) {
       if (sq.partials) sq.partials[(P * 2 + st) * sq.channels + ncl] = t;
     }
   }
+#endif
 }
 
 // ---- generic direct path: any channel counts, one thread per output element, f32 slab out ----
@@ -384,7 +447,9 @@ inline int reduce_rows(int64_t mout, int N) {
 
 struct Plan {
   bool mfma;
+  bool wide;
   int rb;
+  int bm;
   int bn;
   int nsplit;
   int tiles_m, tiles_n, phases;
@@ -403,8 +468,11 @@ bool make_plan(const AdnIgemmDesc* d, Plan* pl) {
   pl->mout = msmall * pl->phases;
   const int taps = d->geom == ADN_GEMM_S2 ? 16 : 4;
   const int epc = 16 / esz;
-  const bool aligned = (d->C0 % epc == 0) && (d->C1 % epc == 0) && ((taps * Cin) % bk == 0) && (d->N % 64 == 0) &&
-                       (d->seg[0].channels % 64 == 0) && (d->seg[1].channels % 64 == 0);
+  // wide: every K-step lies inside one tap of one source; narrow: single source, several taps per K-step
+  pl->wide = (d->C0 % bk == 0) && (d->C1 % bk == 0);
+  const bool narrow_ok = (d->C1 == 0) && (d->C0 % epc == 0) && ((taps * Cin) % bk == 0);
+  const bool aligned = (pl->wide || narrow_ok) && (d->N % 64 == 0) && (d->seg[0].channels % 64 == 0) &&
+                       (d->seg[1].channels % 64 == 0);
   pl->mfma = aligned;
   if (!aligned) {
     pl->bn = 0;
@@ -417,7 +485,12 @@ bool make_plan(const AdnIgemmDesc* d, Plan* pl) {
     return true;
   }
   pl->bn = (d->N % 128 == 0 && d->seg[0].channels % 128 == 0) ? 128 : 64;
-  pl->tiles_m = (int)adn_cdiv(msmall, BM);
+  // 256-row tiles (8 waves, 3-stage ring) when they still give every CU a workgroup; else 128-row tiles
+  // (only worth it for long K loops: with K <= 1024 two 128-row workgroups per CU overlap each other's
+  //  prologue/epilogue better: measured 685 vs 621 TFLOP/s on L1 forward)
+  pl->bm = (adn_cdiv(msmall, 256) * (d->N / pl->bn) * pl->phases >= 256 && taps * Cin / bk >= 32) ? 256 : 128;
+  if (const char* e = getenv("ADN_IGEMM_BM")) pl->bm = atoi(e) == 256 ? 256 : 128;   // tuning knob
+  pl->tiles_m = (int)adn_cdiv(msmall, pl->bm);
   pl->tiles_n = d->N / pl->bn;
   pl->kpt = 0;
   pl->ksteps = taps * Cin / bk;
@@ -442,20 +515,36 @@ bool make_plan(const AdnIgemmDesc* d, Plan* pl) {
   return true;
 }
 
-template <typename T, int BN, int GEOM>
+template <typename T, int BM_, int BN, int GEOM, bool WIDE>
 int launch_mfma(const KParams& kp, const Plan& pl, hipStream_t st) {
-  const int stage = 2 * (BM + BN) * 128;
-  const int epil = BM * (BN + 4) * 4;
+  const int stage = (BM_ == 256 ? 3 : 2) * (BM_ + BN) * 128;
+  const int epil = BM_ * (BN + 4) * 4;
   const int lds = stage > epil ? stage : epil;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_mfma_kernel<T, BN, GEOM>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_mfma_kernel<T, BM_, BN, GEOM, WIDE>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
   dim3 grid(pl.tiles_m * pl.tiles_n, pl.phases, pl.nsplit);
-  hipLaunchKernelGGL((igemm_mfma_kernel<T, BN, GEOM>), grid, dim3(256), lds, st, kp);
+  hipLaunchKernelGGL((igemm_mfma_kernel<T, BM_, BN, GEOM, WIDE>), grid, dim3(BM_ * 2), lds, st, kp);
   return 0;
+}
+
+template <typename T, int GEOM, bool WIDE>
+void dispatch_mfma2(const KParams& kp, const Plan& pl, hipStream_t st) {
+  if (pl.bm == 256) {
+    if (pl.bn == 128) launch_mfma<T, 256, 128, GEOM, WIDE>(kp, pl, st);
+    else launch_mfma<T, 256, 64, GEOM, WIDE>(kp, pl, st);
+  } else {
+    if (pl.bn == 128) launch_mfma<T, 128, 128, GEOM, WIDE>(kp, pl, st);
+    else launch_mfma<T, 128, 64, GEOM, WIDE>(kp, pl, st);
+  }
+}
+template <typename T, int GEOM>
+void dispatch_mfma(const KParams& kp, const Plan& pl, hipStream_t st) {
+  if (pl.wide) dispatch_mfma2<T, GEOM, true>(kp, pl, st);
+  else dispatch_mfma2<T, GEOM, false>(kp, pl, st);
 }
 
 template <typename T>
@@ -481,13 +570,8 @@ int run(const AdnIgemmDesc* d, const Plan& pl, hipStream_t st) {
   kp.seg[1] = d->seg[1];
   kp.slab = reinterpret_cast<float*>(d->workspace);
   if (pl.mfma) {
-    if (d->geom == ADN_GEMM_S2) {
-      if (pl.bn == 128) launch_mfma<T, 128, ADN_GEMM_S2>(kp, pl, st);
-      else launch_mfma<T, 64, ADN_GEMM_S2>(kp, pl, st);
-    } else {
-      if (pl.bn == 128) launch_mfma<T, 128, ADN_GEMM_T2>(kp, pl, st);
-      else launch_mfma<T, 64, ADN_GEMM_T2>(kp, pl, st);
-    }
+    if (d->geom == ADN_GEMM_S2) dispatch_mfma<T, ADN_GEMM_S2>(kp, pl, st);
+    else dispatch_mfma<T, ADN_GEMM_T2>(kp, pl, st);
     ADN_CHECK_LAUNCH();
     if (pl.nsplit > 1) {
       hipLaunchKernelGGL((igemm_reduce_kernel<T>),

@@ -7,7 +7,7 @@
 // them with ds_read_b64_tr_b16 (hardware transpose read, cdna_hip_programming.md T10), the exact
 // f32 path with ds_read_b32.  LDS tiles are [pixel][128 channels] with the 32-byte granule index
 // XOR-ed by f(row) = (row&3) | ((row>>3)&1)<<2, which makes both the transposed reads (8 rows x 32 B
-// per half-wave) and the staging writes conflict free.  Output tile 128(r) x 128(tap,c columns);
+// per half-wave) conflict free; the tiles are filled by LDS-DMA with the swizzle on the source address.  Output tile 128(r) x 128(tap,c columns);
 // the pixel range is split over grid.z into f32 slabs that a second kernel sums (deterministic).
 #include "adn_common.h"
 
@@ -25,10 +25,14 @@ struct WParams {
   int c_valid;    // gathered channels actually stored (compact [R][16][c_valid]); == C0+C1 normally
 };
 
+// 128 zero bytes: LDS-DMA source for rows beyond M / padded taps / the upper half of an R=64 tile
+__device__ u32x4_t adn_wg_zero_page[8];
+
 __device__ __forceinline__ int swz_f(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
-template <typename T>
+template <typename T, bool FAST>
 __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins exist only in the device pass
   constexpr int EPC = 16 / (int)sizeof(T);
   constexpr int BKP = sizeof(T) == 2 ? 64 : 32;       // pixels per step
   constexpr int ROWB = 128 * (int)sizeof(T);          // bytes per LDS row
@@ -49,72 +53,140 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
   const int Hs = p.Hs, Ws = p.Ws, Hl = 2 * Hs, Wl = 2 * Ws;
   const int C = p.C0 + p.C1;
 
-  const int chunk = tid % CPRW;
+  // LDS-DMA staging (global_load_lds_dwordx4): wave w writes 1 KiB = RPP/4 consecutive tile rows per pass,
+  // lane l lands on row (l / CPRW) of that group, physical chunk (l % CPRW).  The granule swizzle is applied
+  // on the SOURCE side: the lane fetches the logical chunk whose swizzled position is its physical chunk.
+  // f(row) depends on the pass only through (row>>3)&1, which alternates with the pass for the f32 tile
+  // (8 rows per pass), hence NV = 2 source variants there.
+  const int pc = tid % CPRW;
   const int prow0 = tid / CPRW;
-
-  // plain operand: channel range fixed per thread
-  const int r_el = tile_r * 128 + chunk * EPC;
-  const bool r_ok = r_el < p.R0 + p.R1;      // R may be a multiple of 64: upper half tile is zero
-  const T* psrc;
-  int Rsrc, roff;
-  if (r_el < p.R0) {
-    psrc = reinterpret_cast<const T*>(p.plain0);
-    Rsrc = p.R0;
-    roff = r_el;
-  } else {
-    psrc = reinterpret_cast<const T*>(p.plain1);
-    Rsrc = p.R1;
-    roff = r_el - p.R0;
-  }
-  // gathered operand: (tap, channel) fixed per thread
-  const int gcol = tile_c * 128 + chunk * EPC;
-  const int tap = gcol / C;
-  const int cch = gcol - tap * C;
-  const int ky = tap >> 2, kx = tap & 3;
-  const T* gsrc;
-  int Csrc, coff;
-  if (cch < p.C0) {
-    gsrc = reinterpret_cast<const T*>(p.gath0);
-    Csrc = p.C0;
-    coff = cch;
-  } else {
-    gsrc = reinterpret_cast<const T*>(p.gath1);
-    Csrc = p.C1;
-    coff = cch - p.C0;
+  constexpr int NV = sizeof(T) == 2 ? 1 : 2;
+  const T* zero = reinterpret_cast<const T*>(adn_wg_zero_page);
+  const T* psrc[NV];
+  int Rsrc[NV];
+  bool r_ok[NV];
+  const T* gsrc[NV];
+  int Csrc[NV], ky[NV], kx[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int row = prow0 + RPP * v;
+    const int lc = (((pc >> 1) ^ swz_f(row)) << 1) | (pc & 1);
+    const int r_el = tile_r * 128 + lc * EPC;
+    r_ok[v] = r_el < p.R0 + p.R1;      // R may be a multiple of 64: upper half tile is zero
+    if (r_el < p.R0) {
+      psrc[v] = reinterpret_cast<const T*>(p.plain0) + r_el;
+      Rsrc[v] = p.R0;
+    } else {
+      psrc[v] = reinterpret_cast<const T*>(p.plain1) + (r_el - p.R0);
+      Rsrc[v] = p.R1;
+    }
+    const int gcol = tile_c * 128 + lc * EPC;
+    const int tap = gcol / C;
+    const int cch = gcol - tap * C;
+    ky[v] = tap >> 2;
+    kx[v] = tap & 3;
+    if (cch < p.C0) {
+      gsrc[v] = reinterpret_cast<const T*>(p.gath0) + cch;
+      Csrc[v] = p.C0;
+    } else {
+      gsrc[v] = reinterpret_cast<const T*>(p.gath1) + (cch - p.C0);
+      Csrc[v] = p.C1;
+    }
   }
 
   const int s_begin = (int)(((int64_t)p.steps * split) / p.nsplit);
   const int s_end = (int)(((int64_t)p.steps * (split + 1)) / p.nsplit);
 
-  u32x4_t rp[PASSES], rg[PASSES];
-  auto load_step = [&](int s) {
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  // ---- FAST addressing (power-of-two image, >= BKP pixels per image, tile-uniform sources) ----
+  // address = descriptor base (SGPR) + voffset (per lane, constant over the pixel loop) + soffset (scalar per
+  // step).  For pixel m = s*BKP + r the gathered pixel (2i, 2j) has linear index 4m - 2j, which splits into a
+  // scalar part of s and a lane constant of r; border taps are recognised by scalar compares combined with
+  // lane-constant masks, and get voffset 0x80000000 (hardware range check -> the DMA writes zeros).
+  constexpr unsigned OOB = 0x80000000u;
+  constexpr int ESZ = (int)sizeof(T);
+  unsigned pvoff[PASSES], gvoff[PASSES];
+  bool m_y0[PASSES], m_y1[PASSES], m_x0[PASSES], m_x1[PASSES], m_c[PASSES];
+  __amdgpu_buffer_rsrc_t rsp, rsg;
+  int Rs_u = 0, Cs_u = 0, lgWs = 0;
+  if constexpr (FAST) {
+    lgWs = 31 - __builtin_clz((unsigned)Ws);
+    const bool psecond = tile_r * 128 >= p.R0;
+    Rs_u = psecond ? p.R1 : p.R0;
+    const char* pb = reinterpret_cast<const char*>(psecond ? p.plain1 : p.plain0);
+    const bool gsecond = (C >= 128) && ((tile_c * 128) % C) >= p.C0;
+    Cs_u = gsecond ? p.C1 : p.C0;
+    const char* gb = reinterpret_cast<const char*>(gsecond ? p.gath1 : p.gath0) - (int64_t)(Wl + 1) * Cs_u * ESZ;
+    rsp = __builtin_amdgcn_make_buffer_rsrc((void*)pb, 0, 0x7ffffff0, 0x00020000);
+    rsg = __builtin_amdgcn_make_buffer_rsrc((void*)gb, 0, 0x7ffffff0, 0x00020000);
+    const bool rows_in_line = Ws >= BKP;          // a step stays inside one image row
+    const int q = rows_in_line ? 1 : BKP / Ws;    // image rows per step otherwise
 #pragma unroll
     for (int k = 0; k < PASSES; ++k) {
-      const int m = s * BKP + prow0 + RPP * k;
-      u32x4_t vp = {0u, 0u, 0u, 0u}, vg = {0u, 0u, 0u, 0u};
-      if (m < p.Msmall) {
-        if (r_ok) vp = *reinterpret_cast<const u32x4_t*>(psrc + (int64_t)m * Rsrc + roff);
-        const int b = m / (Hs * Ws);
-        const int rem = m - b * (Hs * Ws);
-        const int i = rem / Ws;
-        const int j = rem - i * Ws;
-        const int iy = 2 * i - 1 + ky, ix = 2 * j - 1 + kx;
-        if ((unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl) {
-          const int64_t pix = ((int64_t)b * Hl + iy) * Wl + ix;
-          vg = *reinterpret_cast<const u32x4_t*>(gsrc + pix * Csrc + coff);
-        }
-      }
-      rp[k] = vp;
-      rg[k] = vg;
+      const int v = k % NV;
+      const int r = prow0 + RPP * k;
+      const int row = prow0 + RPP * v;
+      const int lc = (((pc >> 1) ^ swz_f(row)) << 1) | (pc & 1);
+      const int r_el = tile_r * 128 + lc * EPC;
+      const int roff = r_el - (psecond ? p.R0 : 0);
+      pvoff[k] = r_ok[v] ? (unsigned)((r * Rs_u + roff) * ESZ) : OOB;
+      const int gcol = tile_c * 128 + lc * EPC;
+      const int tap = gcol / C;
+      const int cch = gcol - tap * C - (gsecond ? p.C0 : 0);
+      const int jx = r & (Ws - 1);
+      const int L = rows_in_line ? 2 * r : 4 * r - 2 * jx;
+      gvoff[k] = (unsigned)(((L + ky[v] * Wl + kx[v]) * Cs_u + cch) * ESZ);
+      const int a = r >> lgWs;                    // image row inside the step (0 when rows_in_line)
+      m_y0[k] = (ky[v] == 0) && (rows_in_line || a == 0);
+      m_y1[k] = (ky[v] == 3) && (rows_in_line || a == q - 1);
+      m_x0[k] = rows_in_line && (kx[v] == 0) && (r == 0);
+      m_x1[k] = rows_in_line && (kx[v] == 3) && (r == BKP - 1);
+      m_c[k] = !rows_in_line && (((kx[v] == 0) && jx == 0) || ((kx[v] == 3) && jx == Ws - 1));
     }
-  };
-  auto store_step = [&](int buf) {
+  }
+
+  auto issue_step = [&](int s, int buf) {
+    char* pdst = Ps + buf * TILE + wave * 1024;
+    char* gdst = Gs + buf * TILE + wave * 1024;
+    if constexpr (FAST) {
+      const int m0 = s * BKP;
+      const bool rows_in_line = Ws >= BKP;
+      const int q = rows_in_line ? 1 : BKP / Ws;
+      const int sj = rows_in_line ? (m0 & (Ws - 1)) : 0;
+      const int si = (m0 >> lgWs) & (Hs - 1);                 // first image row of the step
+      const bool top = si == 0, bot = si == Hs - q;
+      const bool left = rows_in_line && sj == 0, right = rows_in_line && sj == Ws - BKP;
+      const int psoff = m0 * Rs_u * ESZ;
+      const int gsoff = (4 * m0 - 2 * sj) * Cs_u * ESZ;
 #pragma unroll
-    for (int k = 0; k < PASSES; ++k) {
-      const int row = prow0 + RPP * k;
-      const int phys = (((chunk >> 1) ^ swz_f(row)) << 1) | (chunk & 1);
-      *reinterpret_cast<u32x4_t*>(Ps + buf * TILE + row * ROWB + phys * 16) = rp[k];
-      *reinterpret_cast<u32x4_t*>(Gs + buf * TILE + row * ROWB + phys * 16) = rg[k];
+      for (int k = 0; k < PASSES; ++k) {
+        const bool inval = m_c[k] || (top && m_y0[k]) || (bot && m_y1[k]) || (left && m_x0[k]) || (right && m_x1[k]);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsp, (lptr_t)(pdst + k * (RPP * ROWB)), 16, pvoff[k], psoff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsg, (lptr_t)(gdst + k * (RPP * ROWB)), 16,
+                                                 inval ? OOB : gvoff[k], gsoff, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < PASSES; ++k) {
+        const int v = k % NV;
+        const int m = s * BKP + prow0 + RPP * k;
+        const T* pp = zero;
+        const T* gg = zero;
+        if (m < p.Msmall) {
+          if (r_ok[v]) pp = psrc[v] + (int64_t)m * Rsrc[v];
+          const int b = m / (Hs * Ws);
+          const int rem = m - b * (Hs * Ws);
+          const int i = rem / Ws;
+          const int j = rem - i * Ws;
+          const int iy = 2 * i - 1 + ky[v], ix = 2 * j - 1 + kx[v];
+          if ((unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl)
+            gg = gsrc[v] + (((int64_t)b * Hl + iy) * Wl + ix) * Csrc[v];
+        }
+        __builtin_amdgcn_global_load_lds((gptr_t)pp, (lptr_t)(pdst + k * (RPP * ROWB)), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)gg, (lptr_t)(gdst + k * (RPP * ROWB)), 16, 0, 0);
+      }
     }
   };
 
@@ -124,17 +196,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  if (s_begin < s_end) {
-    load_step(s_begin);
-    store_step(0);
-  }
-  __syncthreads();
+  if (s_begin < s_end) issue_step(s_begin, 0);
+  __syncthreads();   // drains the LDS-DMA (vmcnt(0)) in front of the barrier
 
   const int fi = lane & 15, fg = lane >> 4;
   for (int s = s_begin; s < s_end; ++s) {
     const int cur = (s - s_begin) & 1;
-    const bool more = (s + 1) < s_end;
-    if (more) load_step(s + 1);
+    if (s + 1 < s_end) issue_step(s + 1, cur ^ 1);
     const char* Pb = Ps + cur * TILE;
     const char* Gb = Gs + cur * TILE;
     if constexpr (sizeof(T) == 2) {
@@ -196,7 +264,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
       }
     }
-    if (more) store_step(cur ^ 1);
     __syncthreads();
   }
 
@@ -236,6 +303,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
       }
     }
   }
+#endif
 }
 
 // generic path: one thread per (output element, split)
@@ -273,7 +341,23 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(WParams p, int pix_pe
 }
 
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float* slab, float* out, int64_t n, int nsplit) {
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+  // n is a multiple of 4 (R*16*c with R % 64 == 0); 4 independent accumulator chains hide the load latency
+  const int64_t n4 = n >> 2;
+  const f32x4_t* s4 = reinterpret_cast<const f32x4_t*>(slab);
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (int64_t)gridDim.x * 256) {
+    f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+    int s = 0;
+    for (; s + 4 <= nsplit; s += 4) {
+      a0 += s4[(int64_t)(s + 0) * n4 + e];
+      a1 += s4[(int64_t)(s + 1) * n4 + e];
+      a2 += s4[(int64_t)(s + 2) * n4 + e];
+      a3 += s4[(int64_t)(s + 3) * n4 + e];
+    }
+    for (; s < nsplit; ++s) a0 += s4[(int64_t)s * n4 + e];
+    reinterpret_cast<f32x4_t*>(out)[e] = (a0 + a1) + (a2 + a3);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t e = (n4 << 2) + threadIdx.x;
     float v = 0.f;
     for (int s = 0; s < nsplit; ++s) v += slab[(int64_t)s * n + e];
     out[e] = v;
@@ -282,6 +366,7 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* slab, float*
 
 struct WPlan {
   bool mfma;
+  bool fast;
   int nsplit, steps, tiles_r, tiles_c, pix_per_split;
   int64_t out_elems, slab_bytes;
 };
@@ -296,8 +381,14 @@ void make_wplan(const AdnWgradDesc* d, WPlan* pl) {
   const bool aligned = (R % 64 == 0) && (d->R0 % epc == 0) && ((16 * C) % 128 == 0) && (C % epc == 0) &&
                        (d->C0 % epc == 0) && (C >= 128 ? (C % 128 == 0) : (128 % C == 0));
   pl->mfma = aligned;
+  pl->fast = false;
   if (aligned) {
     const int bkp = d->dtype == ADN_BF16 ? 64 : 32;
+    auto pow2 = [](int x) { return x > 0 && (x & (x - 1)) == 0; };
+    pl->fast = pow2(d->Hs) && pow2(d->Ws) && d->Hs * d->Ws >= bkp && (d->R1 == 0 || d->R0 % 128 == 0) &&
+               (d->C1 == 0 || (d->C0 % 128 == 0 && C % 128 == 0)) &&
+               msmall * 4 * (d->C0 > d->C1 ? d->C0 : d->C1) * 4 < (1ll << 31) &&
+               msmall * (d->R0 > d->R1 ? d->R0 : d->R1) * 4 < (1ll << 31);     // 32-bit scalar byte offsets
     pl->steps = (int)adn_cdiv(msmall, bkp);
     pl->tiles_r = (int)adn_cdiv(R, 128);
     pl->tiles_c = 16 * C / 128;
@@ -350,18 +441,25 @@ int wrun(const AdnWgradDesc* d, const WPlan& pl, hipStream_t st) {
     constexpr int lds = stage > epil ? stage : epil;
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_kernel<T>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_kernel<T, true>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_kernel<T, false>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       attr_set = true;
     }
-    hipLaunchKernelGGL((wgrad_mfma_kernel<T>), dim3(pl.tiles_r * pl.tiles_c, 1, pl.nsplit), dim3(256), lds, st, p);
+    if (pl.fast)
+      hipLaunchKernelGGL((wgrad_mfma_kernel<T, true>), dim3(pl.tiles_r * pl.tiles_c, 1, pl.nsplit), dim3(256), lds, st,
+                         p);
+    else
+      hipLaunchKernelGGL((wgrad_mfma_kernel<T, false>), dim3(pl.tiles_r * pl.tiles_c, 1, pl.nsplit), dim3(256), lds, st,
+                         p);
   } else {
     hipLaunchKernelGGL((wgrad_direct_kernel<T>), dim3((unsigned)adn_cdiv(pl.out_elems, 256), pl.nsplit), dim3(256),
                        0, st, p, pl.pix_per_split);
   }
   ADN_CHECK_LAUNCH();
   if (pl.nsplit > 1) {
-    int64_t blocks = adn_cdiv(pl.out_elems, 256);
+    int64_t blocks = adn_cdiv(adn_cdiv(pl.out_elems, 4), 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, st,
                        reinterpret_cast<const float*>(d->workspace), d->dw, pl.out_elems, pl.nsplit);

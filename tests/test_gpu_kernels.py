@@ -66,6 +66,8 @@ SHAPES = [
     (3, 128, 0, 128, 2),     # MFMA, tiny M -> split-K + reduce
     (8, 64, 0, 128, 64),     # MFMA, >=256 tiles -> fused LDS epilogue (BN=128)
     (8, 64, 64, 64, 32),     # MFMA, fused epilogue for the 4-phase T2 geometry (BN=64)
+    (16, 64, 0, 128, 64),    # MFMA, 256-row tiles / 8 waves / 3-stage LDS-DMA ring (S2: 256 tiles)
+    (16, 64, 64, 64, 32),    # same for T2 (64 tiles x 4 phases), BN=64
     (2, 6, 0, 10, 4),        # generic direct path
     (1, 3, 5, 1, 5),         # generic, two sources, single output channel, odd size
 ]
@@ -195,7 +197,8 @@ def test_wgrad(dtype, shape):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize('shape', [(2, 64, 0, 128, 16), (3, 128, 0, 128, 2), (2, 6, 0, 10, 4), (8, 64, 0, 128, 64)])
+@pytest.mark.parametrize('shape', [(2, 64, 0, 128, 16), (3, 128, 0, 128, 2), (2, 6, 0, 10, 4), (8, 64, 0, 128, 64),
+                                   (16, 64, 0, 128, 64)])
 def test_epilogue_z_stats_and_bn(dtype, shape):
     """Z_STATS epilogue + adn_bn_fwd_finalize + adn_bn_act == conv -> BatchNorm2d(train) -> LeakyReLU / ReLU."""
     B, C0, _, N, Hs = shape
@@ -231,7 +234,7 @@ def test_epilogue_z_stats_and_bn(dtype, shape):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize('shape', [(2, 128, 0, 64, 8), (2, 10, 0, 6, 4), (8, 128, 0, 64, 64)])
+@pytest.mark.parametrize('shape', [(2, 128, 0, 64, 8), (2, 10, 0, 6, 4), (8, 128, 0, 64, 64), (16, 128, 0, 64, 64)])
 def test_epilogue_bwd_two_segments(dtype, shape):
     """convT dgrad with ReLU mask, split into a skip segment (no stats) and an up segment (BN-bwd stats),
     then accumulate a second contribution with a LeakyReLU mask."""

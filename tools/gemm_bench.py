@@ -1,0 +1,83 @@
+"""Micro-benchmark of single implicit-GEMM / wgrad launches at the unet_256 B=32 layer shapes (tuning aid).
+
+    python tools/gemm_bench.py [--iters 20] [--only NAME]
+Prints TFLOP/s per shape from HIP events around `iters` back-to-back launches (random bf16 data).
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from audio_depth_estimation_amd import kernels as K  # noqa: E402
+
+DEV = 'cuda'
+T = torch.bfloat16
+B = 32
+# name, geom, Hs, C0, C1, N
+IGEMM = [
+    ('L1_fwd', 0, 64, 64, 0, 128), ('L2_fwd', 0, 32, 128, 0, 256), ('L3_fwd', 0, 16, 256, 0, 512),
+    ('L4_fwd', 0, 8, 512, 0, 512),
+    ('D1_fwd', 1, 64, 128, 128, 64), ('D2_fwd', 1, 32, 256, 256, 128), ('D3_fwd', 1, 16, 512, 512, 256),
+    ('D4_fwd', 1, 8, 512, 512, 512),
+    ('D1_dgrad', 0, 64, 64, 0, 256), ('D2_dgrad', 0, 32, 128, 0, 512), ('L2_dgrad', 1, 32, 256, 0, 128),
+    ('L1_dgrad', 1, 64, 128, 0, 64),
+]
+# name, Hs, R0, R1, C
+WGRAD = [('L1_wgrad', 64, 128, 0, 64), ('L2_wgrad', 32, 256, 0, 128), ('L3_wgrad', 16, 512, 0, 256),
+         ('D1_wgrad', 64, 128, 128, 64), ('D2_wgrad', 32, 256, 256, 128), ('D3_wgrad', 16, 512, 512, 256)]
+
+
+def timeit(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--iters', type=int, default=20)
+    ap.add_argument('--only', default=None)
+    args = ap.parse_args()
+    torch.manual_seed(0)
+    for name, geom, Hs, C0, C1, N in IGEMM:
+        if args.only and args.only not in name:
+            continue
+        hin = 2 * Hs if geom == 0 else Hs
+        in0 = torch.randn(B, hin, hin, C0, device=DEV).to(T)
+        in1 = torch.randn(B, hin, hin, C1, device=DEV).to(T) if C1 else None
+        taps = 16 if geom == 0 else 4
+        w = (torch.randn((1 if geom == 0 else 4) * N * taps * (C0 + C1), device=DEV) * 0.05).to(T)
+        hout = Hs if geom == 0 else 2 * Hs
+        out = torch.empty(B, hout, hout, N, device=DEV, dtype=T)
+        P, wsb = K.igemm_query(T, geom, B, Hs, Hs, C0, C1, N, [N])
+        ws = torch.empty(max(wsb, 16) // 4, device=DEV)
+        part = torch.empty(P * 2 * N, device=DEV)
+        fn = lambda: K.igemm(T, geom, B, Hs, Hs, in0, in1, w, N, 1, [K.Seg(N, out0=out, partials=part)], ws)
+        t = timeit(fn, args.iters)
+        fl = 2.0 * B * Hs * Hs * N * 16 * (C0 + C1)
+        print(f'{name:10s} M={B*Hs*Hs*(1 if geom == 0 else 4):7d} N={N:4d} K={taps*(C0+C1):5d}  {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF/s', flush=True)
+    for name, Hs, R0, R1, C in WGRAD:
+        if args.only and args.only not in name:
+            continue
+        p0 = torch.randn(B, Hs, Hs, R0, device=DEV).to(T)
+        p1 = torch.randn(B, Hs, Hs, R1, device=DEV).to(T) if R1 else None
+        g = torch.randn(B, 2 * Hs, 2 * Hs, C, device=DEV).to(T)
+        dw = torch.empty((R0 + R1) * 16 * C, device=DEV)
+        ws = torch.empty(max(K.wgrad_workspace_bytes(T, B, Hs, Hs, R0, R1, C, 0), 16) // 4, device=DEV)
+        fn = lambda: K.wgrad(T, B, Hs, Hs, p0, p1, g, None, dw, ws)
+        t = timeit(fn, args.iters)
+        fl = 2.0 * B * Hs * Hs * (R0 + R1) * 16 * C
+        print(f'{name:10s} M={B*Hs*Hs:7d} R={R0+R1:4d} C={C:4d}        {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF/s (incl. slab sum)', flush=True)
+
+
+if __name__ == '__main__':
+    main()
