@@ -90,6 +90,7 @@ _PROTOS = {
     'adn_frontend_workspace_bytes': (c_int64, [c_int32, c_int32, c_int32]),
     'adn_frontend': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int64,
                                c_void_p]),
+    'adn_resize_bilinear': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
 }
 
 _lib = None

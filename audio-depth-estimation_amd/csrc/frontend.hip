@@ -230,3 +230,13 @@ extern "C" int adn_frontend(const float* wave, int32_t B, int32_t T, int32_t mod
   ADN_CHECK_LAUNCH();
   return ADN_OK;
 }
+
+extern "C" int adn_resize_bilinear(const float* src, int32_t planes, int32_t H, int32_t W, int32_t S, int32_t antialias,
+                                   float* out, void* stream) {
+  ADN_CHECK_ARG(src && out && planes > 0 && H > 0 && W > 0 && S > 0, "adn_resize_bilinear: bad arguments");
+  hipLaunchKernelGGL(fe_resize_kernel, dim3((unsigned)adn_cdiv((int64_t)S * S, 256), planes), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), src, static_cast<const float*>(nullptr), 0, H, W, S, antialias,
+                     0, out);
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}

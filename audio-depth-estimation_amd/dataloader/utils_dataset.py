@@ -1,0 +1,95 @@
+"""Transforms of the data pipeline (mirror of the reference's dataloader/utils_dataset.py).
+
+``get_transform(cfg, convert=False, depth_norm=False)`` keeps the reference signature (:10-28): a composition
+of (ToTensor) -> Resize((S,S)) -> (MinMaxNorm).  Resize runs in libadn (adn_resize_bilinear: bilinear,
+align_corners=False, ``antialias`` explicit because the torchvision default changed across releases and the
+reference pins no version -- SURVEY.md Appendix B item 4; default True).
+"""
+import numpy as np
+import torch
+
+from .. import kernels as K
+
+
+class Resize:
+    def __init__(self, size, antialias=True):
+        self.size = size if isinstance(size, int) else size[0]
+        self.antialias = antialias
+
+    def __call__(self, tensor):
+        dev = tensor.device if tensor.is_cuda else torch.device('cuda', torch.cuda.current_device())
+        src = tensor.detach().to(dev, torch.float32).contiguous()
+        out = torch.empty(src.shape[0], self.size, self.size, dtype=torch.float32, device=dev)
+        K.resize_bilinear(src, self.size, self.antialias, out)
+        return out if tensor.is_cuda else out.cpu()
+
+
+class ToTensor:
+    def __call__(self, x):
+        return x if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(x))
+
+
+class MinMaxNorm(torch.nn.Module):
+    def __init__(self, min, max):
+        super().__init__()
+        assert isinstance(min, (float, tuple)) and isinstance(max, (float, tuple))
+        self.min = torch.tensor(min)
+        self.max = torch.tensor(max)
+
+    def forward(self, tensor):
+        return (tensor - self.min.to(tensor.device)) / (self.max.to(tensor.device) - self.min.to(tensor.device))
+
+
+class Compose:
+    def __init__(self, transforms):
+        self.transforms = list(transforms)
+
+    def __call__(self, x):
+        for t in self.transforms:
+            x = t(x)
+        return x
+
+
+def get_transform(cfg, convert=False, depth_norm=False, antialias=True):
+    transform_list = []
+    if convert:
+        transform_list.append(ToTensor())
+    if 'resize' in cfg.dataset.preprocess:
+        transform_list.append(Resize((cfg.dataset.images_size, cfg.dataset.images_size), antialias=antialias))
+    if depth_norm:
+        transform_list.append(MinMaxNorm(min=0.0, max=float(cfg.dataset.max_depth)))
+    return Compose(transform_list)
+
+
+def resize_nearest_cv2(depth, size):
+    """cv2.resize(depth, (S,S), interpolation=INTER_NEAREST): src index = floor(dst * in / out)."""
+    H, W = depth.shape
+    ys = np.minimum((np.arange(size) * (H / size)).astype(np.int64), H - 1)
+    xs = np.minimum((np.arange(size) * (W / size)).astype(np.int64), W - 1)
+    return depth[ys][:, xs]
+
+
+class GpuAudioFrontend:
+    """Batched audio front-end on the device: raw waveforms [B,2,T] -> network input [B,2,S,S].
+
+    The MI355X-first data path: DataLoader workers only read files (``frontend='raw'`` datasets), the
+    STFT / mel / log / min-max / resize of the whole batch is ONE libadn call (adn_frontend).
+    mode: 'mel_spectrogram' | 'spectrogram' (BV2: log + min-max) | 'bv1' (raw magnitude).
+    """
+    MODES = {'mel_spectrogram': 0, 'spectrogram': 1, 'bv1': 2}
+
+    def __init__(self, mode, size, antialias=True):
+        self.mode = self.MODES[mode]
+        self.size = size
+        self.antialias = antialias
+        self._ws = None
+
+    def __call__(self, wave):
+        wave = wave.contiguous().float()
+        B, _, T = wave.shape
+        need = K.frontend_workspace_bytes(B, T, self.mode) // 4
+        if self._ws is None or self._ws.numel() < need or self._ws.device != wave.device:
+            self._ws = torch.empty(need, dtype=torch.float32, device=wave.device)
+        out = torch.empty(B, 2, self.size, self.size, dtype=torch.float32, device=wave.device)
+        K.frontend(wave, self.mode, self.size, self.antialias, out, self._ws)
+        return out

@@ -441,6 +441,21 @@ class FusedTrainer:
             self.ddp.attach(eng)
         self._ready = True
 
+    def state_dict(self):
+        """Optimizer state (flat Adam moments + step counters) for the checkpoint's 'optimizer' entry."""
+        if not self._ready:
+            return {'kind': self.opt_kind, 'lr': self.lr, 'step': 0}
+        return {'kind': self.opt_kind, 'lr': self.lr, 'betas': self.betas, 'eps': self.eps,
+                'weight_decay': self.weight_decay, 'step': int(self.state[0].item()),
+                'exp_avg': self.exp_avg.detach().cpu(), 'exp_avg_sq': self.exp_avg_sq.detach().cpu()}
+
+    def load_state_dict(self, sd, device):
+        self._setup(device)
+        if 'exp_avg' in sd:
+            self.exp_avg.copy_(sd['exp_avg'])
+            self.exp_avg_sq.copy_(sd['exp_avg_sq'])
+            self.state[0] = float(sd['step'])
+
     def step(self, audio, gt):
         self._calls += 1
         if self._graph is not None:

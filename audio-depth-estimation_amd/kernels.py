@@ -277,3 +277,14 @@ def frontend(wave, mode, S, antialias, out, workspace):
     B, _, T = wave.shape
     _lib.call('adn_frontend', ptr(wave), B, T, mode, S, int(antialias), ptr(out), ptr(workspace),
               workspace.numel() * workspace.element_size(), _stream())
+
+
+def frontend_workspace_bytes(B, T, mode):
+    return _lib.load().adn_frontend_workspace_bytes(B, T, mode)
+
+
+def resize_bilinear(src, S, antialias, out):
+    """src f32 [planes, H, W] -> out f32 [planes, S, S] (align_corners=False, optional antialias)."""
+    _dev(src, out)
+    planes, H, W = src.shape
+    _lib.call('adn_resize_bilinear', ptr(src), planes, H, W, S, int(antialias), ptr(out), _stream())

@@ -1,0 +1,250 @@
+"""U-Net baseline trainer on libadn (mirror of the reference's train.py entry point).
+
+Same command line (flag names, defaults, override precedence yaml -> argparse; /root/reference/train.py:64-135,
+:205-246, :394-417), experiment naming (:288-313), loss assembly (:646-669), hot loop (:633-693: forward,
+masked loss, backward, clip_grad_norm_(1.0), optimizer step), validation metrics (:726-843) and checkpoint
+layout (:600-606, :897-909, :1006-1017: {'epoch','state_dict','optimizer'} under ./checkpoints/<exp>/).
+Differences, all on the device side: the step runs in engine.FusedTrainer (HIP kernels, optional hipGraph),
+the audio front-end runs per BATCH on the device (GpuAudioFrontend), validation metrics are one device
+kernel per batch, and multi-GPU is one process per GPU (torchrun) with RCCL all-reduce instead of
+nn.DataParallel.  Extra flags: --precision {bf16,f32}, --synthetic N (no dataset needed), --graph.
+wandb / PNG visualisation / sequence hold-out plumbing of the reference are logging-only and out of scope.
+
+    python -m audio_depth_estimation_amd.train --dataset batvisionv2 --batch_size 32
+    python -m torch.distributed.run --nproc-per-node 8 -m audio_depth_estimation_amd.train --batch_size 32
+"""
+import argparse
+import os
+import time
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader, Dataset
+
+from . import ddp as addp
+from .config_loader import load_config
+from .dataloader.utils_dataset import GpuAudioFrontend
+from .engine import FusedTrainer
+from .models.unetbaseline_model import *          # noqa: F401,F403  (define_G, nn, torch ... as the reference)
+from .utils_criterion import compute_errors_batch
+
+
+class SyntheticBatvision(Dataset):
+    """BatVision-shaped random items: audio ~ U[0,1), depth 30*U with <10 % invalid."""
+
+    def __init__(self, n, size, max_depth, depth_norm, channels=2):
+        self.n, self.size, self.max_depth, self.depth_norm, self.channels = n, size, max_depth, depth_norm, channels
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, idx):
+        g = torch.Generator().manual_seed(1234 + idx)
+        audio = torch.rand(self.channels, self.size, self.size, generator=g)
+        gt = self.max_depth * torch.rand(1, self.size, self.size, generator=g)
+        gt[gt < 0.1 * self.max_depth] = 0.0
+        return audio, (gt / self.max_depth if self.depth_norm else gt)
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description='Train U-Net model on Batvision dataset for depth estimation (MI355X)')
+    g = p.add_argument_group('Dataset & Model')
+    g.add_argument('--dataset', type=str, default='batvisionv2', choices=['batvisionv1', 'batvisionv2'])
+    g.add_argument('--audio_format', type=str, default=None, choices=['spectrogram', 'mel_spectrogram', 'waveform'])
+    g.add_argument('--eval_img', action='store_true', default=False)
+    g.add_argument('--max_depth', type=float, default=None)
+    g = p.add_argument_group('Training Hyperparameters')
+    g.add_argument('--batch_size', type=int, default=None)
+    g.add_argument('--learning_rate', '--lr', type=float, default=None)
+    g.add_argument('--optimizer', type=str, default=None, choices=['Adam', 'AdamW', 'SGD'])
+    g = p.add_argument_group('Loss Function')
+    g.add_argument('--criterion', type=str, default=None, choices=['L1', 'SIlog', 'Combined'])
+    g.add_argument('--use_silog', type=lambda x: (str(x).lower() == 'true'), default=None)
+    g.add_argument('--silog_lambda', type=float, default=None)
+    g.add_argument('--l1_weight', type=float, default=None)
+    g.add_argument('--silog_weight', type=float, default=None)
+    g = p.add_argument_group('Validation & Logging')
+    g.add_argument('--validation', type=lambda x: (str(x).lower() == 'true'), default=None)
+    g.add_argument('--validation_iter', type=int, default=None)
+    g.add_argument('--save_best_model', action='store_true', default=True)
+    g.add_argument('--best_metric', type=str, default='rmse', choices=['rmse', 'abs_rel', 'delta1', 'mae', 'loss'])
+    g = p.add_argument_group('Experiment Management')
+    g.add_argument('--experiment_name', type=str, default='default')
+    g.add_argument('--checkpoints', type=int, default=None)
+    g = p.add_argument_group('MI355X')
+    g.add_argument('--precision', default='bf16', choices=['bf16', 'f32'])
+    g.add_argument('--synthetic', type=int, default=0, help='train on N synthetic items (no dataset on disk)')
+    g.add_argument('--epochs', type=int, default=None)
+    g.add_argument('--graph', action='store_true', help='replay the step as one hipGraph (single GPU)')
+    return p
+
+
+def resolve_loss(cfg, args):
+    """Criterion / weights with the reference's auto-detection (train.py:394-467)."""
+    if args.criterion is not None:
+        cfg.mode.criterion = args.criterion
+    elif args.l1_weight is not None or args.silog_weight is not None or args.use_silog is not None:
+        cfg.mode.criterion = 'Combined'
+    for name in ('optimizer', 'silog_lambda', 'l1_weight', 'silog_weight'):
+        if getattr(args, name) is not None:
+            setattr(cfg.mode, name, getattr(args, name))
+    crit = cfg.mode.criterion
+    l1w, sw = getattr(cfg.mode, 'l1_weight', 0.5), getattr(cfg.mode, 'silog_weight', 0.5)
+    lam = getattr(cfg.mode, 'silog_lambda', 0.5)
+    if crit == 'Combined':
+        use_silog = args.use_silog if args.use_silog is not None else (sw != 0.0)
+        if not use_silog:                    # "L1 only (SIlog disabled)"
+            crit, l1w, sw = 'L1', 1.0, 0.0
+    elif crit not in ('L1', 'SIlog'):
+        raise ValueError(f'Unknown criterion: {crit}. Available: L1, SIlog, Combined')
+    return crit, l1w, sw, lam
+
+
+def experiment_name(cfg, args):
+    name = f'{cfg.model.generator}_{cfg.dataset.name}_BS{cfg.mode.batch_size}_Lr{cfg.mode.learning_rate}_{cfg.mode.optimizer}'
+    if args.eval_img:
+        name += '_IMG'
+    if args.max_depth is not None and args.max_depth != 30.0:
+        name += f'_MD{int(args.max_depth)}'
+    return name + '_' + cfg.mode.experiment_name
+
+
+def make_loaders(cfg, args, rank, world):
+    if args.synthetic:
+        S, md, dn = cfg.dataset.images_size, cfg.dataset.max_depth, cfg.dataset.depth_norm
+        train = SyntheticBatvision(args.synthetic, S, md, dn, 3 if args.eval_img else 2)
+        val = SyntheticBatvision(max(1, args.synthetic // 4), S, md, dn, 3 if args.eval_img else 2)
+        fe = None
+    else:
+        if cfg.dataset.name == 'batvisionv1':
+            from .dataloader.BatvisionV1_Dataset import BatvisionV1Dataset
+            train = BatvisionV1Dataset(cfg, cfg.dataset.annotation_file_train, frontend='raw')
+            val = BatvisionV1Dataset(cfg, cfg.dataset.annotation_file_val, frontend='raw')
+            fe = GpuAudioFrontend('bv1', cfg.dataset.images_size)
+        else:
+            from .dataloader.BatvisionV2_Dataset import BatvisionV2Dataset
+            train = BatvisionV2Dataset(cfg, cfg.dataset.annotation_file_train, use_image=args.eval_img, frontend='raw')
+            val = BatvisionV2Dataset(cfg, cfg.dataset.annotation_file_val, use_image=args.eval_img, frontend='raw')
+            mode = 'mel_spectrogram' if 'mel' in cfg.dataset.audio_format else 'spectrogram'
+            fe = None if args.eval_img else GpuAudioFrontend(mode, cfg.dataset.images_size)
+    sampler = torch.utils.data.distributed.DistributedSampler(train, world, rank, shuffle=cfg.mode.shuffle) \
+        if world > 1 else None
+    tl = DataLoader(train, batch_size=cfg.mode.batch_size, shuffle=cfg.mode.shuffle and sampler is None,
+                    sampler=sampler, num_workers=cfg.mode.num_threads, drop_last=True)
+    vl = DataLoader(val, batch_size=cfg.mode.batch_size, shuffle=cfg.mode.shuffle, num_workers=cfg.mode.num_threads)
+    return tl, vl, fe, sampler
+
+
+def validate(model, loader, fe, cfg, device):
+    """Per-sample metrics of train.py:782-838 (clip pred to [eps, max_depth], gt >= 0), one kernel per batch."""
+    model.eval()
+    rows = []
+    md = float(cfg.dataset.max_depth)
+    eps = 1e-3 if cfg.dataset.depth_norm else 1e-6
+    with torch.no_grad():
+        for audio, gt in loader:
+            audio, gt = audio.to(device), gt.to(device)
+            if fe is not None:
+                audio = fe(audio)
+            pred = model(audio)
+            if cfg.dataset.depth_norm:
+                pred, gt = pred * md, gt * md
+            rows.append(compute_errors_batch(gt.clamp(min=0.0), pred.clamp(eps, md)))
+    model.train()
+    return torch.cat(rows).mean(0).tolist()
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    cfg = load_config(dataset_name=args.dataset, mode='train', experiment_name=args.experiment_name)
+    if args.checkpoints is not None:
+        cfg.mode.checkpoints = args.checkpoints
+    if args.max_depth is not None:
+        cfg.dataset.max_depth = args.max_depth
+    if args.batch_size is not None:
+        cfg.mode.batch_size = args.batch_size
+    if args.learning_rate is not None:
+        if args.learning_rate <= 0:
+            raise ValueError(f'Learning rate must be positive, got {args.learning_rate}')
+        if args.learning_rate > 0.1:
+            raise ValueError(f'ERROR: Learning rate {args.learning_rate} exceeds safe maximum (0.1).')
+        cfg.mode.learning_rate = args.learning_rate
+    if args.audio_format is not None:
+        if args.dataset == 'batvisionv1' and args.audio_format == 'mel_spectrogram':
+            raise ValueError('mel_spectrogram is not supported for batvisionv1. Use \'spectrogram\' or \'waveform\'.')
+        cfg.dataset.audio_format = args.audio_format
+    if args.validation is not None:
+        cfg.mode.validation = args.validation
+    if args.validation_iter is not None:
+        cfg.mode.validation_iter = args.validation_iter
+    if args.epochs is not None:
+        cfg.mode.epochs = args.epochs
+    if cfg.mode.mode != 'train':
+        raise Exception('This script is for training only. Please run test.py for evaluation')
+    if cfg.model.name != 'unet_baseline':
+        raise Exception('This script if for training on unet model only')
+    if not torch.cuda.is_available():
+        raise RuntimeError('train.py runs on libadn HIP kernels: no HIP device is visible (there is no CPU path)')
+
+    rank, world, local = addp.init_from_env()
+    device = torch.device('cuda', local)
+    torch.cuda.set_device(device)
+    crit, l1w, sw, lam = resolve_loss(cfg, args)
+    exp = experiment_name(cfg, args)
+    train_loader, val_loader, fe, sampler = make_loaders(cfg, args, rank, world)
+
+    input_nc = 3 if args.eval_img else 2
+    model = define_G(cfg, input_nc=input_nc, output_nc=1, ngf=64, netG='unet_256', norm='batch', use_dropout=False,  # noqa: F405
+                     init_type='normal', init_gain=0.02, gpu_ids=[])
+    model.compute_dtype = torch.bfloat16 if args.precision == 'bf16' else torch.float32
+    model = model.to(device).train()
+    start_epoch = 1
+    ckpt_dir = os.path.join('./checkpoints', exp)
+    if cfg.mode.checkpoints is not None:
+        ck = torch.load(os.path.join(ckpt_dir, f'checkpoint_{cfg.mode.checkpoints}.pth'), map_location=device)
+        model.load_state_dict({k[7:] if k.startswith('module.') else k: v for k, v in ck['state_dict'].items()})
+        start_epoch = ck['epoch'] + 1
+    reducer = addp.GradientAllReducer() if world > 1 else None
+    max_depth = cfg.dataset.max_depth if cfg.dataset.max_depth else 30.0
+    trainer = FusedTrainer(model.engine(), crit, l1w, sw, lam, max_depth=max_depth, optimizer=cfg.mode.optimizer,
+                           lr=cfg.mode.learning_rate, clip_norm=1.0, mask_mode='ne0', ddp=reducer)
+    if reducer is not None:
+        model.engine().bind_parameters()
+        reducer.broadcast_parameters(model.engine().flat_p)
+    elif args.graph:
+        trainer.enable_graph(after_steps=3)
+
+    best = 0.0 if args.best_metric == 'delta1' else float('inf')
+    for epoch in range(start_epoch, cfg.mode.epochs + 1):
+        t0 = time.time()
+        if sampler is not None:
+            sampler.set_epoch(epoch)
+        losses = []
+        for audio, gt in train_loader:
+            audio, gt = audio.to(device, non_blocking=True), gt.to(device, non_blocking=True)
+            if fe is not None:
+                audio = fe(audio)
+            loss, _ = trainer.step(audio, gt)
+            losses.append(loss.detach().clone())
+        if losses and rank == 0:
+            print(f'Epoch {epoch}: Train Loss: {torch.stack(losses).mean().item():.6f}, Time: {time.time() - t0:.1f}s')
+        if cfg.mode.validation and epoch % cfg.mode.validation_iter == 0 and rank == 0:
+            abs_rel, rmse, d1, d2, d3, log10, mae = validate(model, val_loader, fe, cfg, device)
+            print(f'Val - RMSE: {rmse:.3f}, ABS_REL: {abs_rel:.3f}, Log10: {log10:.3f}, Delta1: {d1:.3f}, '
+                  f'Delta2: {d2:.3f}, Delta3: {d3:.3f}, MAE: {mae:.3f}')
+            cur = {'rmse': rmse, 'abs_rel': abs_rel, 'delta1': d1, 'mae': mae, 'loss': rmse}[args.best_metric]
+            if args.save_best_model and ((cur > best) if args.best_metric == 'delta1' else (cur < best)):
+                best = cur
+                os.makedirs(ckpt_dir, exist_ok=True)
+                torch.save({'epoch': epoch, 'state_dict': model.state_dict(), 'optimizer': trainer.state_dict(),
+                            'best_metric': args.best_metric, 'best_metric_value': best},
+                           os.path.join(ckpt_dir, 'best_model.pth'))
+        if epoch % cfg.mode.saving_checkpoints == 0 and rank == 0:
+            os.makedirs(ckpt_dir, exist_ok=True)
+            torch.save({'epoch': epoch, 'state_dict': model.state_dict(), 'optimizer': trainer.state_dict()},
+                       os.path.join(ckpt_dir, f'checkpoint_{epoch}.pth'))
+    return model
+
+
+if __name__ == '__main__':
+    main()

@@ -211,6 +211,9 @@ int64_t adn_frontend_workspace_bytes(int32_t B, int32_t T, int32_t mode);
 int adn_frontend(const float* wave, int32_t B, int32_t T, int32_t mode, int32_t S,
                  int32_t antialias, float* out, void* workspace, int64_t workspace_bytes,
                  void* stream);
+/* transforms.Resize((S,S)) alone (utils_dataset.py:18-20): src f32 [planes][H][W] -> out [planes][S][S]. */
+int adn_resize_bilinear(const float* src, int32_t planes, int32_t H, int32_t W, int32_t S,
+                        int32_t antialias, float* out, void* stream);
 
 #ifdef __cplusplus
 }
