@@ -51,15 +51,56 @@ __global__ __launch_bounds__(256) void pack_t2_kernel(const float* master, int X
   }
 }
 
+// one thread per pixel: C coalesced plane reads, one contiguous Cpad-element write
 template <typename T>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* src, T* dst, int B, int C, int Cpad,
                                                            int64_t HW) {
-  const int64_t n = (int64_t)B * Cpad * HW;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
-    const int c = (int)(e % Cpad);
-    const int64_t pix = e / Cpad;
+  const int64_t npix = (int64_t)B * HW;
+  for (int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x; pix < npix; pix += (int64_t)gridDim.x * 256) {
     const int64_t b = pix / HW, hw = pix - b * HW;
-    ElemTraits<T>::store(dst + e, c < C ? src[(b * C + c) * HW + hw] : 0.0f);
+    for (int c0 = 0; c0 < Cpad; c0 += 8) {
+      float f[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) f[k] = (c0 + k < C) ? src[(b * C + c0 + k) * HW + hw] : 0.0f;
+      if (c0 + 8 <= Cpad && (Cpad & 7) == 0) {
+        store8<T>(dst, pix * Cpad + c0, f);
+      } else {
+        for (int k = 0; k < 8 && c0 + k < Cpad; ++k) ElemTraits<T>::store(dst + pix * Cpad + c0 + k, f[k]);
+      }
+    }
+  }
+}
+
+// every layer's T2 pack in one launch: blockIdx -> layer by a linear scan of the (tiny) table
+template <typename T>
+__global__ __launch_bounds__(256) void pack_t2_multi_kernel(const float* flat_master, const int64_t* table, int layers,
+                                                            T* t2_base) {
+  __shared__ float tile[32][33];
+  int l = 0;
+  while (l + 1 < layers && (int64_t)blockIdx.x >= table[(l + 1) * 5 + 4]) ++l;
+  const float* master = flat_master + table[l * 5 + 0];
+  const int X = (int)table[l * 5 + 1], Y = (int)table[l * 5 + 2];
+  T* t2 = t2_base + table[l * 5 + 3];
+  const int local = (int)((int64_t)blockIdx.x - table[l * 5 + 4]);
+  const int tiles_xy = ((X + 31) / 32) * ((Y + 31) / 32);
+  const int tap = local / tiles_xy, txy = local % tiles_xy;
+  const int kh = tap >> 2, kw = tap & 3;
+  const int ph = (kh & 1) ? 0 : 1, ty = (kh == 3 || kh == 2) ? 1 : 0;
+  const int pw = (kw & 1) ? 0 : 1, tx = (kw == 3 || kw == 2) ? 1 : 0;
+  const int phase = ph * 2 + pw, t = ty * 2 + tx;
+  const int tiles_y = (Y + 31) / 32;
+  const int x0 = (txy / tiles_y) * 32, y0 = (txy % tiles_y) * 32;
+  const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int x = x0 + ly + 8 * r, y = y0 + lx;
+    tile[ly + 8 * r][lx] = (x < X && y < Y) ? master[((int64_t)x * 16 + tap) * Y + y] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int y = y0 + ly + 8 * r, x = x0 + lx;
+    if (x < X && y < Y) ElemTraits<T>::store(t2 + (((int64_t)phase * Y + y) * 4 + t) * X + x, tile[lx][ly + 8 * r]);
   }
 }
 template <typename T>
@@ -240,7 +281,7 @@ extern "C" int adn_nchw_to_nhwc(const float* src, void* dst, int32_t B, int32_t 
   ADN_CHECK_ARG(src && dst && B > 0 && C > 0 && c_pad >= C && H > 0 && W > 0, "adn_nchw_to_nhwc: bad arguments");
   ADN_CHECK_ARG(dtype == ADN_F32 || dtype == ADN_BF16, "adn_nchw_to_nhwc: bad dtype %d", dtype);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const int64_t n = (int64_t)B * c_pad * H * W;
+  const int64_t n = (int64_t)B * H * W;
   if (dtype == ADN_BF16)
     hipLaunchKernelGGL((nchw_to_nhwc_kernel<uint16_t>), dim3(blocks_for(n)), dim3(256), 0, st, src,
                        reinterpret_cast<uint16_t*>(dst), B, C, c_pad, (int64_t)H * W);
@@ -333,6 +374,22 @@ extern "C" int adn_bn_bwd_apply(void* g, const void* z, int64_t pixels, int32_t 
     hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(blocks_for(work)), dim3(256), 0, st,
                        reinterpret_cast<float*>(g), reinterpret_cast<const float*>(z), pixels, C, scale, mean, istd,
                        coef);
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}
+
+extern "C" int adn_pack_t2_multi(const float* flat_master, const int64_t* table, int32_t layers, int64_t total_blocks,
+                                 int32_t dtype, void* t2_base, void* stream) {
+  ADN_CHECK_ARG(flat_master && table && layers > 0 && total_blocks > 0 && t2_base, "adn_pack_t2_multi: bad arguments");
+  ADN_CHECK_ARG(dtype == ADN_F32 || dtype == ADN_BF16, "adn_pack_t2_multi: bad dtype %d", dtype);
+  ADN_CHECK_ARG(total_blocks < (1ll << 31), "adn_pack_t2_multi: too many blocks");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == ADN_BF16)
+    hipLaunchKernelGGL((pack_t2_multi_kernel<uint16_t>), dim3((unsigned)total_blocks), dim3(256), 0, st, flat_master,
+                       table, layers, reinterpret_cast<uint16_t*>(t2_base));
+  else
+    hipLaunchKernelGGL((pack_t2_multi_kernel<float>), dim3((unsigned)total_blocks), dim3(256), 0, st, flat_master, table,
+                       layers, reinterpret_cast<float*>(t2_base));
   ADN_CHECK_LAUNCH();
   return ADN_OK;
 }

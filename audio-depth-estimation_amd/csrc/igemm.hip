@@ -46,18 +46,21 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// BM = 128: 4 waves (2x2), 2 LDS stages, 2 workgroups per CU  (small-M / split-K layers)
-// BM = 256: 8 waves (4x2), 3 LDS stages, 1 workgroup per CU: the DMA of steps s+1 and s+2 stays in
-//           flight across the per-step barrier (counted s_waitcnt vmcnt, raw s_barrier).
-template <typename T, int BM, int BN, int GEOM, bool WIDE>
-__global__ __launch_bounds__(BM * 2, 2) void igemm_mfma_kernel(KParams p) {
+// Tile configurations (waves are BM/64 x NWN, each wave owns a 64 x BN/NWN sub-tile):
+//   128 x 128, 2x2 waves, 2 LDS stages, 2 workgroups per CU   small-M / split-K / short-K layers
+//   128 x  64, 2x2 waves, 2 stages                             narrow N with small M
+//   256 x  64, 4x1 waves, 2 stages, 2 workgroups per CU        N = 64: every wave keeps a 64x64 sub-tile
+//   256 x 128, 4x2 waves, 3 stages, 1 workgroup per CU         long K: the DMA of steps s+1 and s+2 stays in
+//             flight across the per-step barrier (counted s_waitcnt vmcnt, raw s_barrier)
+template <typename T, int BM, int BN, int NWN, int GEOM, bool WIDE>
+__global__ __launch_bounds__(BM * NWN, 2) void igemm_mfma_kernel(KParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins exist only in the device pass; the host needs the stub only
-  constexpr int NTHR = BM * 2;              // 64 threads per 64x(BN/2) wave tile, 2 wave columns
+  constexpr int NTHR = BM * NWN;            // 64 threads per 64 x (BN/NWN) wave tile
   constexpr int NW = NTHR / 64;
-  constexpr int STAGES = BM == 256 ? 3 : 2;
+  constexpr int STAGES = (BM == 256 && NWN == 2) ? 3 : 2;
   constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
   constexpr int BK = 8 * EPC;               // elements per K-step (128 bytes)
-  constexpr int WN = BN / 2;                // wave tile columns
+  constexpr int WN = BN / NWN;              // wave tile columns
   constexpr int NT = WN / 16;
   constexpr int MT = 4;
   constexpr int RPASS = NTHR / 8;           // tile rows filled per loader pass (8 rows per wave-instruction)
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_mfma_kernel(KParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / NWN, wn = wave % NWN;
   const int nwg = p.tiles_m * p.tiles_n;
   const int wg = xcd_remap(blockIdx.x, nwg);
   const int tile_n = wg % p.tiles_n;
@@ -488,7 +491,8 @@ bool make_plan(const AdnIgemmDesc* d, Plan* pl) {
   // 256-row tiles (8 waves, 3-stage ring) when they still give every CU a workgroup; else 128-row tiles
   // (only worth it for long K loops: with K <= 1024 two 128-row workgroups per CU overlap each other's
   //  prologue/epilogue better: measured 685 vs 621 TFLOP/s on L1 forward)
-  pl->bm = (adn_cdiv(msmall, 256) * (d->N / pl->bn) * pl->phases >= 256 && taps * Cin / bk >= 32) ? 256 : 128;
+  const bool fills256 = adn_cdiv(msmall, 256) * (d->N / pl->bn) * pl->phases >= 256;
+  pl->bm = (fills256 && (pl->bn == 64 || taps * Cin / bk >= 32)) ? 256 : 128;
   if (const char* e = getenv("ADN_IGEMM_BM")) pl->bm = atoi(e) == 256 ? 256 : 128;   // tuning knob
   pl->tiles_m = (int)adn_cdiv(msmall, pl->bm);
   pl->tiles_n = d->N / pl->bn;
@@ -515,30 +519,30 @@ bool make_plan(const AdnIgemmDesc* d, Plan* pl) {
   return true;
 }
 
-template <typename T, int BM_, int BN, int GEOM, bool WIDE>
+template <typename T, int BM_, int BN, int NWN, int GEOM, bool WIDE>
 int launch_mfma(const KParams& kp, const Plan& pl, hipStream_t st) {
-  const int stage = (BM_ == 256 ? 3 : 2) * (BM_ + BN) * 128;
+  const int stage = ((BM_ == 256 && NWN == 2) ? 3 : 2) * (BM_ + BN) * 128;
   const int epil = BM_ * (BN + 4) * 4;
   const int lds = stage > epil ? stage : epil;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_mfma_kernel<T, BM_, BN, GEOM, WIDE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_mfma_kernel<T, BM_, BN, NWN, GEOM, WIDE>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
   dim3 grid(pl.tiles_m * pl.tiles_n, pl.phases, pl.nsplit);
-  hipLaunchKernelGGL((igemm_mfma_kernel<T, BM_, BN, GEOM, WIDE>), grid, dim3(BM_ * 2), lds, st, kp);
+  hipLaunchKernelGGL((igemm_mfma_kernel<T, BM_, BN, NWN, GEOM, WIDE>), grid, dim3(BM_ * NWN), lds, st, kp);
   return 0;
 }
 
 template <typename T, int GEOM, bool WIDE>
 void dispatch_mfma2(const KParams& kp, const Plan& pl, hipStream_t st) {
   if (pl.bm == 256) {
-    if (pl.bn == 128) launch_mfma<T, 256, 128, GEOM, WIDE>(kp, pl, st);
-    else launch_mfma<T, 256, 64, GEOM, WIDE>(kp, pl, st);
+    if (pl.bn == 128) launch_mfma<T, 256, 128, 2, GEOM, WIDE>(kp, pl, st);
+    else launch_mfma<T, 256, 64, 1, GEOM, WIDE>(kp, pl, st);
   } else {
-    if (pl.bn == 128) launch_mfma<T, 128, 128, GEOM, WIDE>(kp, pl, st);
-    else launch_mfma<T, 128, 64, GEOM, WIDE>(kp, pl, st);
+    if (pl.bn == 128) launch_mfma<T, 128, 128, 2, GEOM, WIDE>(kp, pl, st);
+    else launch_mfma<T, 128, 64, 2, GEOM, WIDE>(kp, pl, st);
   }
 }
 template <typename T, int GEOM>

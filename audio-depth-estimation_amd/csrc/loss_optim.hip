@@ -182,7 +182,7 @@ __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v,
 __global__ __launch_bounds__(256) void optimizer_step_kernel(float* params, const float* grads, float* m, float* v,
                                                              int64_t n, int kind, float lr, float b1, float b2,
                                                              float eps, float wd, int use_clip,
-                                                             const double* state) {
+                                                             const double* state, uint16_t* w16) {
   const float coef = use_clip ? (float)state[4] : 1.0f;
   const float step_size = (float)((double)lr / state[1]);
   const float inv_sqrt_bc2 = (float)(1.0 / sqrt(state[2]));
@@ -211,6 +211,11 @@ __global__ __launch_bounds__(256) void optimizer_step_kernel(float* params, cons
       v4[i] = vv;
     }
     p4[i] = p;
+    if (w16) {   // bf16 mirror of the updated parameters = the S2 GEMM operand of the next step
+      const uint32_t lo = (uint32_t)f32_to_bf16_bits(p[0]) | ((uint32_t)f32_to_bf16_bits(p[1]) << 16);
+      const uint32_t hi = (uint32_t)f32_to_bf16_bits(p[2]) | ((uint32_t)f32_to_bf16_bits(p[3]) << 16);
+      reinterpret_cast<uint2*>(w16)[i] = make_uint2(lo, hi);
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const int64_t i = (n4 << 2) + threadIdx.x;
@@ -223,6 +228,7 @@ __global__ __launch_bounds__(256) void optimizer_step_kernel(float* params, cons
       m[i] = mk;
       v[i] = vk;
     }
+    if (w16) w16[i] = f32_to_bf16_bits(params[i]);
   }
 }
 
@@ -324,7 +330,7 @@ extern "C" int adn_grad_norm(const float* grads, int64_t n, float max_norm, doub
 
 extern "C" int adn_optimizer_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
                                   int32_t kind, float lr, float beta1, float beta2, float eps, float weight_decay,
-                                  int32_t use_clip, double* state, void* stream) {
+                                  int32_t use_clip, double* state, void* bf16_copy, void* stream) {
   ADN_CHECK_ARG(params && grads && n > 0 && state, "adn_optimizer_step: bad arguments");
   ADN_CHECK_ARG(kind >= 0 && kind <= 2, "adn_optimizer_step: bad kind %d", kind);
   ADN_CHECK_ARG(kind == 2 || (exp_avg && exp_avg_sq), "adn_optimizer_step: Adam needs moment buffers");
@@ -338,7 +344,8 @@ extern "C" int adn_optimizer_step(float* params, const float* grads, float* exp_
   if (nb > 8192) nb = 8192;
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(optimizer_step_kernel, dim3((unsigned)nb), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq,
-                     n, kind, lr, beta1, beta2, eps, weight_decay, use_clip, state);
+                     n, kind, lr, beta1, beta2, eps, weight_decay, use_clip, state,
+                     reinterpret_cast<uint16_t*>(bf16_copy));
   ADN_CHECK_LAUNCH();
   return ADN_OK;
 }

@@ -85,8 +85,12 @@ class UNetEngine:
             p.data = view
             p.grad = None
         self.flat_p, self.flat_g, self.param_meta, self.total = flat_p, flat_g, meta, total
+        # bf16 mirror of the parameters (same offsets): the fused optimizer writes it, the S2 GEMM operands
+        # of the unpadded layers are views into it
+        self.flat_w16 = torch.zeros(total, dtype=torch.bfloat16, device=dev) if self.dtype == torch.bfloat16 else None
         self.offset = {id(p): off for p, off, _ in meta}
         self.weights_dirty = True
+        self.s2_fresh = False
         self._shape_key = None
 
     @staticmethod
@@ -108,6 +112,12 @@ class UNetEngine:
         return sum(p._version for p, _, _ in self.param_meta)
 
     def _pack_weights(self):
+        """Cast/pack the f32 master weights into the GEMM operand forms.
+
+        S2 operands: views of the bf16 mirror (written by the fused optimizer; re-cast here only when the
+        parameters were changed from outside) or the f32 master itself; padded edge layers get their own
+        small pack.  T2 operands: every layer in ONE launch (adn_pack_t2_multi).
+        """
         T = self.dtype
         for lv in self.levels:
             for key in ('down', 'up'):
@@ -115,12 +125,15 @@ class UNetEngine:
                 X, Y = w.shape[0], w.shape[1]
                 master = self._flat_slice(self.flat_p, w)
                 ypad = lv[key + '_ypad']
-                if T == torch.float32 and ypad == Y:
+                if ypad != Y:
+                    K.pack_weights(master, X, Y, T, lv[key + '_s2'], None, y_pad=ypad)
+                elif T == torch.float32:
                     lv[key + '_s2'] = master                       # channels_last memory == S2 operand
-                    K.pack_weights(master, X, Y, T, None, lv[key + '_t2'])
-                else:
-                    K.pack_weights(master, X, Y, T, lv[key + '_s2'], lv[key + '_t2'], y_pad=ypad)
+                elif not self.s2_fresh:
+                    K.pack_weights(master, X, Y, T, lv[key + '_s2'], None)
+        K.pack_t2_multi(self.flat_p, self.t2_table, self.t2_layers, self.t2_blocks, T, self.t2_all)
         self.weights_dirty = False
+        self.s2_fresh = False
         self._packed_version = self._version_sum()
 
     # ------------------------------------------------------------------ buffers
@@ -172,13 +185,13 @@ class UNetEngine:
             else:
                 lv['out'] = torch.empty(B, 2 * hs, 2 * wsz, cu_out, **f32)
                 lv['dz0'] = big(cu_out_p)
-            # packed weights
-            if T != torch.float32 or cd_in_p != cd_in:
-                lv['down_s2'] = torch.empty(cd_out, 16, cd_in_p, dtype=T, device=dev)
-            if T != torch.float32 or cu_out_p != cu_out:
-                lv['up_s2'] = torch.empty(cu_in, 16, cu_out_p, dtype=T, device=dev)
-            lv['down_t2'] = torch.empty(4, cd_in, 4, cd_out, dtype=T, device=dev)
-            lv['up_t2'] = torch.empty(4, cu_out, 4, cu_in, dtype=T, device=dev)
+            # packed weights: S2 = view of the bf16 parameter mirror (unpadded bf16 layers), own buffer when
+            # padded, the f32 master itself on the exact path; T2 = slices of one flat buffer (below)
+            for wk, X, Y, Yp in (('down', cd_out, cd_in, cd_in_p), ('up', cu_in, cu_out, cu_out_p)):
+                if Yp != Y:
+                    lv[wk + '_s2'] = torch.empty(X, 16, Yp, dtype=T, device=dev)
+                elif T != torch.float32:
+                    lv[wk + '_s2'] = self._flat_slice(self.flat_w16, lv[wk].weight).view(X, 16, Y)
             # GEMM plans: partial rows + workspace
             c_up0 = cd_out
             c_up1 = cu_in - cd_out
@@ -210,6 +223,24 @@ class UNetEngine:
                 lv['bpart_u'] = torch.empty(self.levels[i - 1]['P_gu'] * 2 * lv['cu_out'], **f32)
             if lv['bn_d'] is not None:
                 lv['bpart_d'] = torch.empty(self.levels[i + 1]['P_gd'] * 2 * lv['cd_out'], **f32)
+        # one flat T2 buffer + the layer table of adn_pack_t2_multi
+        rows, t2_off, blk = [], 0, 0
+        for lv in self.levels:
+            for wk in ('down', 'up'):
+                w = lv[wk].weight
+                X, Y = w.shape[0], w.shape[1]
+                rows.append([self.offset[id(w)], X, Y, t2_off, blk])
+                lv[wk + '_t2_off'] = t2_off
+                t2_off += 16 * X * Y
+                blk += ((X + 31) // 32) * ((Y + 31) // 32) * 16
+        self.t2_all = torch.empty(t2_off, dtype=T, device=dev)
+        for lv in self.levels:
+            for wk in ('down', 'up'):
+                w = lv[wk].weight
+                o = lv[wk + '_t2_off']
+                lv[wk + '_t2'] = self.t2_all[o:o + 16 * w.shape[0] * w.shape[1]]
+        self.t2_table = torch.tensor(rows, dtype=torch.int64, device=dev)
+        self.t2_layers, self.t2_blocks = len(rows), blk
         self.workspace = torch.empty(ws_bytes // 4 + 4, **f32)
         self.red_ws = torch.empty(4096, dtype=torch.float64, device=dev)
         self.weights_dirty = True
@@ -495,6 +526,7 @@ class FusedTrainer:
             K.grad_norm(eng.flat_g, float(self.clip_norm), self.state, self.norm_ws)
         K.optimizer_step(eng.flat_p, eng.flat_g, self.exp_avg, self.exp_avg_sq, self.opt_kind, self.lr,
                          self.betas[0], self.betas[1], self.eps, self.weight_decay, self.clip_norm is not None,
-                         self.state)
+                         self.state, bf16_copy=eng.flat_w16)
         eng.weights_dirty = True
+        eng.s2_fresh = eng.flat_w16 is not None      # the optimizer just refreshed the bf16 S2 operands
         return self.loss[0], pred

@@ -260,10 +260,17 @@ def grad_norm(grads, max_norm, state, workspace):
               workspace.numel() * workspace.element_size(), _stream())
 
 
-def optimizer_step(params, grads, exp_avg, exp_avg_sq, kind, lr, beta1, beta2, eps, weight_decay, use_clip, state):
-    _dev(params, grads, state)
+def optimizer_step(params, grads, exp_avg, exp_avg_sq, kind, lr, beta1, beta2, eps, weight_decay, use_clip, state,
+                   bf16_copy=None):
+    _dev(params, grads, state, bf16_copy)
     _lib.call('adn_optimizer_step', ptr(params), ptr(grads), ptr(exp_avg), ptr(exp_avg_sq), params.numel(), kind, lr,
-              beta1, beta2, eps, weight_decay, int(use_clip), ptr(state), _stream())
+              beta1, beta2, eps, weight_decay, int(use_clip), ptr(state), ptr(bf16_copy), _stream())
+
+
+def pack_t2_multi(flat_master, table, layers, total_blocks, dtype, t2_base):
+    _dev(flat_master, table, t2_base)
+    _lib.call('adn_pack_t2_multi', ptr(flat_master), ptr(table), layers, total_blocks, dtype_code(dtype), ptr(t2_base),
+              _stream())
 
 
 def compute_errors(gt, pred, out7):

@@ -192,10 +192,17 @@ int adn_sum_to_scalar(const void* x, int64_t n, int32_t dtype, float* out, void*
 int adn_grad_norm(const float* grads, int64_t n, float max_norm, double* state, void* workspace,
                   int64_t workspace_bytes, void* stream);
 int64_t adn_grad_norm_workspace_bytes(int64_t n);
-/* kind: 0 AdamW (decoupled decay), 1 Adam (L2 in gradient), 2 SGD. Advances state[0..2]. */
+/* kind: 0 AdamW (decoupled decay), 1 Adam (L2 in gradient), 2 SGD. Advances state[0..2].
+ * bf16_copy (optional, n bf16): mirror of the updated parameters, i.e. next step's S2 GEMM operands. */
 int adn_optimizer_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                        int64_t n, int32_t kind, float lr, float beta1, float beta2, float eps,
-                       float weight_decay, int32_t use_clip, double* state, void* stream);
+                       float weight_decay, int32_t use_clip, double* state, void* bf16_copy,
+                       void* stream);
+/* All T2 (phase-split) weight packs of a network in ONE launch.  table (device, int64 [L][5]):
+ * master offset (floats) into flat_master, X, Y, t2 offset (elements) into t2_base, first block index;
+ * total_blocks = sum over layers of ceil(X/32)*ceil(Y/32)*16. */
+int adn_pack_t2_multi(const float* flat_master, const int64_t* table, int32_t layers,
+                      int64_t total_blocks, int32_t dtype, void* t2_base, void* stream);
 
 /* Evaluation metrics (compute_errors, utils_criterion.py:6-90), one set of 7 floats per sample:
  * (abs_rel, rmse, a1, a2, a3, log_10, mae). gt/pred: [samples][pixels] f32. */
