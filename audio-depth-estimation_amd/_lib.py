@@ -126,9 +126,35 @@ def check(rc: int, what: str = ''):
         raise RuntimeError(f'libadn {what} failed (rc={rc}): {msg}')
 
 
+# Launch-plan recording: while RECORD is a list every successful call is appended as (cfunc, args, name) so
+# that a fixed-shape step can be replayed with one Python loop over prebuilt ctypes arguments (no descriptor
+# rebuilding, ~1.5 us per launch).  Python-side actions (collectives) are recorded with record_py().
+RECORD = None
+
+
 def call(name: str, *args):
     """Call an int-returning entry point and raise on error."""
-    check(getattr(load(), name)(*args), name)
+    fn = getattr(load(), name)
+    check(fn(*args), name)
+    if RECORD is not None:
+        RECORD.append((fn, args, name))
+
+
+def record_py(fn):
+    """Run a Python action now and, while recording, make it part of the launch plan."""
+    fn()
+    if RECORD is not None:
+        RECORD.append((None, fn, 'py'))
+
+
+def replay(plan):
+    for fn, args, name in plan:
+        if fn is None:
+            args()
+        else:
+            rc = fn(*args)
+            if rc != 0:
+                check(rc, name)
 
 
 def ptr(t):

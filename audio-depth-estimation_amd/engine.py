@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import torch
 
+from . import _lib
 from . import kernels as K
 from ._lib import EPI_ACT, EPI_BWD, EPI_FINAL, EPI_Z_STATS, GEMM_S2, GEMM_T2
 
@@ -321,7 +322,8 @@ class UNetEngine:
     # ------------------------------------------------------------------ backward
     def _ready(self, param):
         if self.on_grad_ready is not None:
-            self.on_grad_ready(self.offset[id(param)])
+            off = self.offset[id(param)]
+            _lib.record_py(lambda: self.on_grad_ready(off))
 
     def backward(self, gout):
         """gout: d loss / d output, f32 [B, Cout, H, W].  Fills flat_g (all parameters)."""
@@ -384,7 +386,7 @@ class UNetEngine:
                                 z=pv['zd'], mean=pv['mean_d'], istd=pv['istd_d'], partials=pv['bpart_d'])
                 K.igemm(T, GEMM_T2, B, hs, wsz, lv['Gd'], None, lv['down_t2'], lv['cd_in'], EPI_BWD, [seg], ws)
         if self.on_grad_ready is not None:
-            self.on_grad_ready(0)
+            _lib.record_py(lambda: self.on_grad_ready(0))
 
 
 class _UNetFunction(torch.autograd.Function):
@@ -442,7 +444,15 @@ class FusedTrainer:
         self._ready = False
         self._graph = None
         self._graph_after = None
+        self._plan = None
+        self._plan_after = None
         self._calls = 0
+
+    def enable_launch_plan(self, after_steps=3):
+        """Record the step's launches once (after ``after_steps`` eager steps) and replay the prebuilt ctypes
+        calls afterwards: the low-overhead eager mode used with the data-parallel reducer, whose collectives
+        stay ordinary torch.distributed calls inside the plan."""
+        self._plan_after = after_steps
 
     def enable_graph(self, after_steps=3):
         """Capture the whole step into one hipGraph after ``after_steps`` eager steps (fixed batch shape).
@@ -489,6 +499,20 @@ class FusedTrainer:
 
     def step(self, audio, gt):
         self._calls += 1
+        if self._plan is not None:
+            self._g_audio.copy_(audio)
+            self._g_gt.copy_(gt)
+            _lib.replay(self._plan)
+            return self._g_out
+        if self._plan_after is not None and self._calls > self._plan_after and self._ready:
+            self._g_audio, self._g_gt = audio.clone(), gt.contiguous().float().clone()
+            _lib.RECORD = []
+            try:
+                self._g_out = self._step_impl(self._g_audio, self._g_gt)
+                self._plan = _lib.RECORD
+            finally:
+                _lib.RECORD = None
+            return self._g_out
         if self._graph is not None:
             self._g_audio.copy_(audio)
             self._g_gt.copy_(gt)
@@ -513,15 +537,15 @@ class FusedTrainer:
         if self.gout is None or self.gout.shape != pred.shape:
             self.gout = torch.empty_like(pred)
         K.loss_stats(pred, gt, self.scale, self.mask_mode, 1e-6, self.stats, self.loss_ws)
-        if self.ddp is not None:
-            self.ddp.all_reduce_loss_stats(self.stats)     # one global-batch loss, as under DataParallel
+        if self.ddp is not None:      # one global-batch loss, as under DataParallel
+            _lib.record_py(lambda: self.ddp.all_reduce_loss_stats(self.stats))
         K.loss_finish(pred, gt, self.scale, self.mask_mode, 1e-6, self.stats, self.criterion, self.l1_weight,
                       self.silog_weight, self.silog_lambda, self.loss, self.gout)
         if self.ddp is not None:
-            self.ddp.begin_backward()
+            _lib.record_py(self.ddp.begin_backward)
         eng.backward(self.gout)
         if self.ddp is not None:
-            self.ddp.finish()
+            _lib.record_py(self.ddp.finish)
         if self.clip_norm is not None:
             K.grad_norm(eng.flat_g, float(self.clip_norm), self.state, self.norm_ws)
         K.optimizer_step(eng.flat_p, eng.flat_g, self.exp_avg, self.exp_avg_sq, self.opt_kind, self.lr,

@@ -111,7 +111,7 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N > 1')
-    device = torch.device('cuda', local)
+    device = torch.device('cuda', local % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(device)
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
 
@@ -146,9 +146,11 @@ def main():
     barrier()
     prof, K.PROFILE = K.PROFILE, None
     if use_graph:
-        trainer.enable_graph(after_steps=0)
-        trainer.step(*batches[0])       # capture + first replay (untimed)
-        barrier()
+        trainer.enable_graph(after_steps=0)          # N=1: the whole step is one hipGraph
+    else:
+        trainer.enable_launch_plan(after_steps=0)    # N>1: prebuilt launch list, collectives stay torch.distributed
+    trainer.step(*batches[0])           # capture / record (untimed)
+    barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss, _ = trainer.step(*batches[i % len(batches)])
@@ -179,7 +181,7 @@ def main():
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': 'unetbaseline_model unet_256 (ngf 64) train step, BatVisionV2-shaped 256x256, '
                                    f'batch {B}/GPU, Combined L1+SIlog loss, clip 1.0, AdamW',
-                       'global_batch': world * B, 'image_size': S, 'launch': 'hipGraph' if use_graph else 'eager',
+                       'global_batch': world * B, 'image_size': S, 'launch': 'hipGraph' if use_graph else 'launch-plan',
                        'parallelism': f'dp{world}' + (' (RCCL bucketed grad all-reduce)' if world > 1 else '')},
             'roofline': {'bound': 'mfma', 'kernel': {'igemm': 'igemm_mfma_kernel', 'wgrad': 'wgrad_mfma_kernel'}.get(dom, dom),
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,

@@ -195,7 +195,7 @@ def test_engine_reuses_buffers_and_graph_step_matches_eager():
     audio = torch.rand(2, 2, 128, 128, generator=g).to(DEV)
     gt = (30 * torch.rand(2, 1, 128, 128, generator=g)).to(DEV)
     finals = []
-    for use_graph in (False, True):
+    for use_graph in (False, True, 'plan'):
         torch.manual_seed(0)
         model = _build('unet_128', 64, False, torch.bfloat16)
         with torch.no_grad():
@@ -203,7 +203,9 @@ def test_engine_reuses_buffers_and_graph_step_matches_eager():
         model.train()
         eng = model.engine()
         tr = FusedTrainer(eng, 'Combined', 0.237, 0.637, 0.869, lr=0.002, clip_norm=1.0)
-        if use_graph:
+        if use_graph == 'plan':
+            tr.enable_launch_plan(after_steps=2)
+        elif use_graph:
             tr.enable_graph(after_steps=2)
         for _ in range(5):
             loss, _ = tr.step(audio, gt)
@@ -214,3 +216,4 @@ def test_engine_reuses_buffers_and_graph_step_matches_eager():
         torch.cuda.synchronize()
         finals.append(eng.flat_p.detach().clone())
     assert torch.equal(finals[0], finals[1])        # deterministic kernels: graph replay == eager, bit for bit
+    assert torch.equal(finals[0], finals[2])        # ... and so is the recorded launch plan
