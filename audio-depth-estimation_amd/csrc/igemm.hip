@@ -75,11 +75,15 @@ __global__ __launch_bounds__(BM * NWN, 2) void igemm_mfma_kernel(KParams p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / NWN, wn = wave % NWN;
-  const int nwg = p.tiles_m * p.tiles_n;
-  const int wg = xcd_remap(blockIdx.x, nwg);
+  // XCD-contiguous block order with the 4 transposed-conv phases of a tile adjacent (they gather the same
+  // input pixels: measured 5x re-fetch of the input from beyond L2 when phases were separate grid slices)
+  constexpr int NPH = GEOM == ADN_GEMM_T2 ? 4 : 1;
+  const int nwg = p.tiles_m * p.tiles_n * NPH;
+  const int wg0 = xcd_remap(blockIdx.x, nwg);
+  const int phase = wg0 % NPH;
+  const int wg = wg0 / NPH;
   const int tile_n = wg % p.tiles_n;
   const int tile_m = wg / p.tiles_n;
-  const int phase = blockIdx.y;
   const int ph = phase >> 1, pw = phase & 1;
   const int split = blockIdx.z;
 
@@ -530,7 +534,7 @@ int launch_mfma(const KParams& kp, const Plan& pl, hipStream_t st) {
                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  dim3 grid(pl.tiles_m * pl.tiles_n, pl.phases, pl.nsplit);
+  dim3 grid(pl.tiles_m * pl.tiles_n * pl.phases, 1, pl.nsplit);
   hipLaunchKernelGGL((igemm_mfma_kernel<T, BM_, BN, NWN, GEOM, WIDE>), grid, dim3(BM_ * NWN), lds, st, kp);
   return 0;
 }

@@ -47,9 +47,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int tile_c = blockIdx.x % p.tiles_c;
-  const int tile_r = blockIdx.x / p.tiles_c;
-  const int split = blockIdx.z;
+  // XCD-contiguous order: all output tiles of one pixel split run on the same XCD and share the staged
+  // operands through its L2 (blocks b and b+8 share an XCD)
+  const int ntile = p.tiles_r * p.tiles_c;
+  const int nblk = ntile * p.nsplit;
+  const int bq = nblk >> 3, br = nblk & 7, bx = blockIdx.x & 7;
+  const int lid = (bx < br ? bx * (bq + 1) : br * (bq + 1) + (bx - br) * bq) + (blockIdx.x >> 3);
+  const int tile_c = lid % p.tiles_c;
+  const int tile_r = (lid / p.tiles_c) % p.tiles_r;
+  const int split = lid / ntile;
   const int Hs = p.Hs, Ws = p.Ws, Hl = 2 * Hs, Wl = 2 * Ws;
   const int C = p.C0 + p.C1;
 
@@ -448,11 +454,9 @@ int wrun(const AdnWgradDesc* d, const WPlan& pl, hipStream_t st) {
       attr_set = true;
     }
     if (pl.fast)
-      hipLaunchKernelGGL((wgrad_mfma_kernel<T, true>), dim3(pl.tiles_r * pl.tiles_c, 1, pl.nsplit), dim3(256), lds, st,
-                         p);
+      hipLaunchKernelGGL((wgrad_mfma_kernel<T, true>), dim3(pl.tiles_r * pl.tiles_c * pl.nsplit), dim3(256), lds, st, p);
     else
-      hipLaunchKernelGGL((wgrad_mfma_kernel<T, false>), dim3(pl.tiles_r * pl.tiles_c, 1, pl.nsplit), dim3(256), lds, st,
-                         p);
+      hipLaunchKernelGGL((wgrad_mfma_kernel<T, false>), dim3(pl.tiles_r * pl.tiles_c * pl.nsplit), dim3(256), lds, st, p);
   } else {
     hipLaunchKernelGGL((wgrad_direct_kernel<T>), dim3((unsigned)adn_cdiv(pl.out_elems, 256), pl.nsplit), dim3(256),
                        0, st, p, pl.pix_per_split);
