@@ -137,18 +137,24 @@ def call(name: str, *args):
     fn = getattr(load(), name)
     check(fn(*args), name)
     if RECORD is not None:
-        RECORD.append((fn, args, name))
+        RECORD.append((fn, args, name, {}))
+
+
+def annotate(**meta):
+    """Attach metadata (e.g. algorithmic FLOPs) to the launch that was just recorded."""
+    if RECORD:
+        RECORD[-1][3].update(meta)
 
 
 def record_py(fn):
     """Run a Python action now and, while recording, make it part of the launch plan."""
     fn()
     if RECORD is not None:
-        RECORD.append((None, fn, 'py'))
+        RECORD.append((None, fn, 'py', {}))
 
 
 def replay(plan):
-    for fn, args, name in plan:
+    for fn, args, name, _ in plan:
         if fn is None:
             args()
         else:

@@ -333,7 +333,9 @@ __global__ __launch_bounds__(BM * NWN, 2) void igemm_mfma_kernel(KParams p) {
     }
   }
 
-  if (sg.partials != nullptr && (epi == ADN_EPI_Z_STATS || epi == ADN_EPI_BWD)) {
+  // (workgroup-uniform condition: a 128-wide tile may straddle a segment with stats and one without)
+  if (p.nsplit == 1 && (p.seg[0].partials != nullptr || p.seg[1].partials != nullptr) &&
+      (p.epi == ADN_EPI_Z_STATS || p.epi == ADN_EPI_BWD)) {
     // reduce over the row subsets: lanes sharing cg inside a wave, then the NW waves through LDS.
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -491,7 +493,7 @@ bool make_plan(const AdnIgemmDesc* d, Plan* pl) {
     pl->slab_bytes = pl->mout * d->N * 4;
     return true;
   }
-  pl->bn = (d->N % 128 == 0 && d->seg[0].channels % 128 == 0) ? 128 : 64;
+  pl->bn = (d->N % 128 == 0) ? 128 : 64;     // segments are multiples of 64: an 8-channel group never straddles
   // 256-row tiles (8 waves, 3-stage ring) when they still give every CU a workgroup; else 128-row tiles
   // (only worth it for long K loops: with K <= 1024 two 128-row workgroups per CU overlap each other's
   //  prologue/epilogue better: measured 685 vs 621 TFLOP/s on L1 forward)

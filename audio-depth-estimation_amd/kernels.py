@@ -119,8 +119,11 @@ def igemm(dtype, geom, B, Hs, Ws, in0, in1, w, N, epi, segs, workspace=None, alg
     d = _igemm_desc(dtype, geom, B, Hs, Ws, in0, in1, w, N, epi, segs, workspace)
     ev = _prof_begin()
     _lib.call('adn_igemm', C.byref(d), _stream())
-    if ev is not None:     # 2*M_out*N*K, K = taps*Cin  (S2: 16 taps on B*Hs*Ws pixels; T2: 4 taps on 4x the pixels)
-        _prof_end(ev, 'igemm', 2.0 * B * Hs * Ws * N * 16 * (algo_c if algo_c else d.C0 + d.C1))
+    # algorithmic FLOPs 2*M_out*N*K, K = taps*Cin  (S2: 16 taps on B*Hs*Ws pixels; T2: 4 taps on 4x the pixels)
+    flops = 2.0 * B * Hs * Ws * N * 16 * (algo_c if algo_c else d.C0 + d.C1)
+    _lib.annotate(label='igemm', flops=flops)
+    if ev is not None:
+        _prof_end(ev, 'igemm', flops)
 
 
 def _wgrad_desc(dtype, B, Hs, Ws, plain0, plain1, gath0, gath1, dw, workspace, c_valid=0):
@@ -158,8 +161,10 @@ def wgrad(dtype, B, Hs, Ws, plain0, plain1, gath0, gath1, dw, workspace=None, c_
     d = _wgrad_desc(dtype, B, Hs, Ws, plain0, plain1, gath0, gath1, dw, workspace, c_valid)
     ev = _prof_begin()
     _lib.call('adn_wgrad', C.byref(d), _stream())
+    flops = 2.0 * B * Hs * Ws * (d.R0 + d.R1) * 16 * (c_valid if c_valid else d.C0 + d.C1)
+    _lib.annotate(label='wgrad', flops=flops)
     if ev is not None:
-        _prof_end(ev, 'wgrad', 2.0 * B * Hs * Ws * (d.R0 + d.R1) * 16 * (c_valid if c_valid else d.C0 + d.C1))
+        _prof_end(ev, 'wgrad', flops)
 
 
 def pack_weights(master, X, Y, dtype, s2_out=None, t2_out=None, y_pad=None):

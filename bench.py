@@ -138,19 +138,43 @@ def main():
     for i in range(args.warmup):
         trainer.step(*batches[i % len(batches)])
     barrier()
-    # Kernel-level pass (untimed for the headline number): HIP events around every GEMM launch, on the stream
-    # the kernels run on, over eager steps of the same workload.
-    K.PROFILE = []
-    for i in range(min(args.steps, 5)):
-        trainer.step(*batches[i % len(batches)])
+    # Record the step's launch plan (prebuilt ctypes calls).  N>1 replays it (collectives stay ordinary
+    # torch.distributed calls inside it); N=1 captures the same step into one hipGraph further below.
+    trainer.enable_launch_plan(after_steps=0)
+    trainer.step(*batches[0])
     barrier()
-    prof, K.PROFILE = K.PROFILE, None
+    # Kernel-level pass: the same plan with a HIP event pair around every GEMM launch, recorded on the
+    # stream the kernels run on.  The host replays prebuilt calls, so the GPU queue stays full and the event
+    # intervals are kernel durations (an eager Python loop was host-bound once the kernels got fast).
+    plan = trainer._plan
+    timed = [(i, e[3]) for i, e in enumerate(plan) if e[3].get('label') in ('igemm', 'wgrad')]
+    evs = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for i, _ in timed}
+    prof_steps = min(args.steps, 5)
+    fam = {}
+    for it in range(prof_steps):
+        trainer._g_audio.copy_(batches[it % len(batches)][0])
+        trainer._g_gt.copy_(batches[it % len(batches)][1])
+        for i, (fn, a, name, meta) in enumerate(plan):
+            if i in evs:
+                evs[i][0].record()
+            if fn is None:
+                a()
+            else:
+                fn(*a)
+            if i in evs:
+                evs[i][1].record()
+        torch.cuda.synchronize()
+        for i, meta in timed:
+            acc = fam.setdefault(meta['label'], [0.0, 0.0, 0])
+            acc[0] += meta['flops']
+            acc[1] += evs[i][0].elapsed_time(evs[i][1]) * 1e-3
+            acc[2] += 1
+    barrier()
     if use_graph:
+        trainer._plan, trainer._plan_after = None, None
         trainer.enable_graph(after_steps=0)          # N=1: the whole step is one hipGraph
-    else:
-        trainer.enable_launch_plan(after_steps=0)    # N>1: prebuilt launch list, collectives stay torch.distributed
-    trainer.step(*batches[0])           # capture / record (untimed)
-    barrier()
+        trainer.step(*batches[0])                    # capture + first replay (untimed)
+        barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss, _ = trainer.step(*batches[i % len(batches)])
@@ -163,17 +187,21 @@ def main():
     final_loss = float(loss.item())
 
     if rank == 0:
-        fam = {}
-        for label, flops, e0, e1 in prof:
-            acc = fam.setdefault(label, [0.0, 0.0, 0])
-            acc[0] += flops
-            acc[1] += e0.elapsed_time(e1) * 1e-3
-            acc[2] += 1
         dom = max(fam, key=lambda k: fam[k][1])
         flops, secs, launches = fam[dom]
         achieved = flops / secs / 1e12
         peak = MFMA_PEAK_TF[args.dtype]
         gemm_secs = sum(v[1] for v in fam.values())
+        # HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE in separate runs, read side doubled per MI355X_MICROARCH.md); null when not collected
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic_gemm.json')))
+            rows = [v for k, v in pm.items() if k.startswith(dom)]
+            if rows and args.dtype == 'bf16' and B == 32:
+                traffic = sum(r['launches'] * r['hbm_bytes_per_launch'] for r in rows) / sum(r['launches'] for r in rows)
+        except Exception:
+            traffic = None
         result = {
             'metric': 'depth-maps/sec (train step)', 'value': world * B * args.steps / elapsed,
             'unit': 'depth-maps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -185,9 +213,9 @@ def main():
                        'parallelism': f'dp{world}' + (' (RCCL bucketed grad all-reduce)' if world > 1 else '')},
             'roofline': {'bound': 'mfma', 'kernel': {'igemm': 'igemm_mfma_kernel', 'wgrad': 'wgrad_mfma_kernel'}.get(dom, dom),
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-                         'traffic': None, 'launches': launches,
+                         'traffic': traffic, 'launches': launches,
                          'avg_launch_ms': 1e3 * secs / launches,
-                         'gemm_ms_per_step': 1e3 * gemm_secs / max(1, min(args.steps, 5)),
+                         'gemm_ms_per_step': 1e3 * gemm_secs / max(1, prof_steps),
                          'all_gemm_tflops': sum(v[0] for v in fam.values()) / gemm_secs / 1e12},
             'final_loss': final_loss,
         }
