@@ -13,8 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libadn.so')
 
 ADN_F32, ADN_BF16 = 0, 1
-GEMM_S2, GEMM_T2 = 0, 1
-EPI_RAW, EPI_Z_STATS, EPI_ACT, EPI_BWD, EPI_FINAL = 0, 1, 2, 3, 4
+GEMM_S2, GEMM_T2, GEMM_S1 = 0, 1, 2
+EPI_RAW, EPI_Z_STATS, EPI_ACT, EPI_BWD, EPI_FINAL, EPI_ADD = 0, 1, 2, 3, 4, 5
 
 c_void_p, c_int32, c_int64, c_float = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -35,6 +35,7 @@ class AdnIgemmDesc(C.Structure):
         ('in0', c_void_p), ('in1', c_void_p), ('w', c_void_p),
         ('epi', c_int32), ('seg', AdnEpiSeg * 2),
         ('workspace', c_void_p), ('workspace_bytes', c_int64),
+        ('ks', c_int32), ('reserved', c_int32),
     ]
 
 
@@ -44,6 +45,7 @@ class AdnWgradDesc(C.Structure):
         ('plain0', c_void_p), ('plain1', c_void_p), ('R0', c_int32), ('R1', c_int32),
         ('gath0', c_void_p), ('gath1', c_void_p), ('C0', c_int32), ('C1', c_int32),
         ('dw', c_void_p), ('workspace', c_void_p), ('workspace_bytes', c_int64), ('c_valid', c_int32),
+        ('geom', c_int32), ('ks', c_int32),
     ]
 
 
@@ -58,6 +60,22 @@ _PROTOS = {
     'adn_wgrad_workspace_bytes': (c_int64, [C.POINTER(AdnWgradDesc)]),
     'adn_wgrad': (C.c_int, [C.POINTER(AdnWgradDesc), c_void_p]),
     'adn_pack_weights': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    'adn_pack_rows': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    'adn_pack_transpose_taps': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p,
+                                          c_void_p]),
+    'adn_maxpool2_fwd': (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    'adn_maxpool2_bwd': (C.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    'adn_upsample2x_fwd': (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    'adn_upsample2x_bwd': (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    'adn_relu_bwd_stats_num_partials': (c_int64, [c_int64, c_int32]),
+    'adn_relu_bwd_stats': (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
+    'adn_head1x1_fwd': (C.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p]),
+    'adn_head1x1_bwd_workspace_bytes': (c_int64, [c_int64, c_int32]),
+    'adn_head1x1_bwd': (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_int64, c_void_p]),
+    'adn_l1tv_workspace_bytes': (c_int64, [c_int64]),
+    'adn_l1tv_stats': (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
+    'adn_l1tv_finish': (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     'adn_nchw_to_nhwc': (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                    c_void_p]),
     'adn_nhwc_to_nchw': (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),

@@ -115,6 +115,53 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* src, float* 
   }
 }
 
+// master [X][T][Y] f32 -> out [X][row_stride] = [X][T][Ypad] (zero padded channels) + zero tail up to row_stride
+template <typename T>
+__global__ __launch_bounds__(256) void pack_rows_kernel(const float* master, int X, int Tn, int Y, int Ypad,
+                                                        int row_stride, T* out) {
+  const int64_t n = (int64_t)X * row_stride;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const int k = (int)(e % row_stride);
+    const int64_t x = e / row_stride;
+    const int t = k / Ypad, y = k - t * Ypad;
+    ElemTraits<T>::store(out + e, (t < Tn && y < Y) ? master[(x * Tn + t) * Y + y] : 0.0f);
+  }
+}
+
+// master [X][T][Y] f32 -> out [Y][row_stride] with out[y][t'*X + x] = master[x][t][y], t' = flip ? T-1-t : t
+// (input-gradient operand of a stride-1 conv: transposed channels, spatially flipped taps); 32x33 LDS tile
+// transpose per tap, rows zero padded to row_stride.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_transpose_taps_kernel(const float* master, int X, int Tn, int Y, int flip,
+                                                                  int row_stride, T* out) {
+  __shared__ float tile[32][33];
+  const int t = blockIdx.y;
+  const int td = flip ? Tn - 1 - t : t;
+  const int tiles_y = (Y + 31) / 32;
+  const int x0 = (blockIdx.x / tiles_y) * 32, y0 = (blockIdx.x % tiles_y) * 32;
+  const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int x = x0 + ly + 8 * r, y = y0 + lx;
+    tile[ly + 8 * r][lx] = (x < X && y < Y) ? master[((int64_t)x * Tn + t) * Y + y] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int y = y0 + ly + 8 * r, x = x0 + lx;
+    if (x < X && y < Y) ElemTraits<T>::store(out + (int64_t)y * row_stride + (int64_t)td * X + x, tile[lx][ly + 8 * r]);
+  }
+  // zero tail of the rows (only the blocks of tap 0 / x-tile 0 do it)
+  if (t == 0 && x0 == 0) {
+    const int tail0 = Tn * X;
+    for (int r = ly; r < 32; r += 8) {
+      const int y = y0 + r;
+      if (y < Y)
+        for (int k = tail0 + lx; k < row_stride; k += 32) ElemTraits<T>::store(out + (int64_t)y * row_stride + k, 0.0f);
+    }
+  }
+}
+
 // one wave per channel: sum partial rows in f64
 __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const float* partials, int64_t P, int C, double count,
                                                               const float* gamma, const float* beta, float eps,
@@ -390,6 +437,40 @@ extern "C" int adn_pack_t2_multi(const float* flat_master, const int64_t* table,
   else
     hipLaunchKernelGGL((pack_t2_multi_kernel<float>), dim3((unsigned)total_blocks), dim3(256), 0, st, flat_master, table,
                        layers, reinterpret_cast<float*>(t2_base));
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}
+
+extern "C" int adn_pack_rows(const float* master, int32_t X, int32_t taps, int32_t Y, int32_t y_pad, int32_t row_stride,
+                             int32_t dtype, void* out, void* stream) {
+  ADN_CHECK_ARG(master && out && X > 0 && taps > 0 && Y > 0 && y_pad >= Y && row_stride >= taps * y_pad,
+                "adn_pack_rows: bad arguments");
+  ADN_CHECK_ARG(dtype == ADN_F32 || dtype == ADN_BF16, "adn_pack_rows: bad dtype %d", dtype);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int64_t n = (int64_t)X * row_stride;
+  if (dtype == ADN_BF16)
+    hipLaunchKernelGGL((pack_rows_kernel<uint16_t>), dim3(blocks_for(n)), dim3(256), 0, st, master, X, taps, Y, y_pad,
+                       row_stride, reinterpret_cast<uint16_t*>(out));
+  else
+    hipLaunchKernelGGL((pack_rows_kernel<float>), dim3(blocks_for(n)), dim3(256), 0, st, master, X, taps, Y, y_pad,
+                       row_stride, reinterpret_cast<float*>(out));
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}
+
+extern "C" int adn_pack_transpose_taps(const float* master, int32_t X, int32_t taps, int32_t Y, int32_t flip,
+                                       int32_t row_stride, int32_t dtype, void* out, void* stream) {
+  ADN_CHECK_ARG(master && out && X > 0 && taps > 0 && Y > 0 && row_stride >= taps * X,
+                "adn_pack_transpose_taps: bad arguments");
+  ADN_CHECK_ARG(dtype == ADN_F32 || dtype == ADN_BF16, "adn_pack_transpose_taps: bad dtype %d", dtype);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)(adn_cdiv(X, 32) * adn_cdiv(Y, 32)), taps);
+  if (dtype == ADN_BF16)
+    hipLaunchKernelGGL((pack_transpose_taps_kernel<uint16_t>), grid, dim3(256), 0, st, master, X, taps, Y, flip,
+                       row_stride, reinterpret_cast<uint16_t*>(out));
+  else
+    hipLaunchKernelGGL((pack_transpose_taps_kernel<float>), grid, dim3(256), 0, st, master, X, taps, Y, flip,
+                       row_stride, reinterpret_cast<float*>(out));
   ADN_CHECK_LAUNCH();
   return ADN_OK;
 }

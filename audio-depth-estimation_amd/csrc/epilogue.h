@@ -16,6 +16,7 @@ __device__ __forceinline__ void epi_scalar(int epi, const AdnEpiSeg& sg, int64_t
   if (epi == ADN_EPI_RAW) {
     reinterpret_cast<float*>(sg.out0)[idx] = v;
   } else if (epi == ADN_EPI_Z_STATS) {
+    if (sg.bias) v += sg.bias[nl];
     ElemTraits<T>::store(reinterpret_cast<T*>(sg.out0) + idx, v);
     s1 += v;
     s2 += v * v;
@@ -36,6 +37,10 @@ __device__ __forceinline__ void epi_scalar(int epi, const AdnEpiSeg& sg, int64_t
       s1 += g;
       s2 += g * ((z - sg.mean[nl]) * sg.istd[nl]);
     }
+  } else if (epi == ADN_EPI_ADD) {
+    float g = v;
+    if (sg.accumulate) g += ElemTraits<T>::load(reinterpret_cast<const T*>(sg.out0) + idx);
+    ElemTraits<T>::store(reinterpret_cast<T*>(sg.out0) + idx, g);
   } else {  // ADN_EPI_FINAL
     float y = v;
     if (sg.bias) y += sg.bias[nl];
@@ -92,7 +97,7 @@ __device__ __forceinline__ void epi_cols_init(int epi, const AdnEpiSeg& sg, int 
       c.a[e] = sg.mean[nl + e];
       c.b[e] = sg.istd[nl + e];
     }
-  } else if (epi == ADN_EPI_FINAL && sg.bias) {
+  } else if ((epi == ADN_EPI_FINAL || epi == ADN_EPI_Z_STATS) && sg.bias) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) c.b[e] = sg.bias[nl + e];
   }
@@ -105,11 +110,14 @@ __device__ __forceinline__ void epi_vec8(int epi, const AdnEpiSeg& sg, const Epi
   if (epi == ADN_EPI_RAW) {
     store8<float>(sg.out0, idx, v);
   } else if (epi == ADN_EPI_Z_STATS) {
-    store8<T>(sg.out0, idx, v);
+    float zb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) zb[e] = v[e] + c.b[e];       // c.b = bias (0 when the conv has none)
+    store8<T>(sg.out0, idx, zb);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      s1[e] += v[e];
-      s2[e] += v[e] * v[e];
+      s1[e] += zb[e];
+      s2[e] += zb[e] * zb[e];
     }
   } else if (epi == ADN_EPI_ACT) {
     float y[8], o[8];
@@ -146,6 +154,17 @@ __device__ __forceinline__ void epi_vec8(int epi, const AdnEpiSeg& sg, const Epi
         s2[e] += g[e] * ((z[e] - c.a[e]) * c.b[e]);
       }
     }
+  } else if (epi == ADN_EPI_ADD) {
+    float g[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = v[e];
+    if (sg.accumulate) {
+      float old[8];
+      load8<T>(sg.out0, idx, old);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] += old[e];
+    }
+    store8<T>(sg.out0, idx, g);
   } else {  // FINAL
     float o[8];
 #pragma unroll

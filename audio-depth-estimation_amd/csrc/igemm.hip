@@ -24,6 +24,8 @@ struct KParams {
   const void* in1;
   const void* w;
   int B, Hs, Ws, C0, C1, N;
+  int ks;         // S1 geometry: kernel side (1 or 3)
+  int wstride;    // elements per packed-weight row (taps*Cin rounded up to the K-step)
   int Msmall;     // B*Hs*Ws
   int kpt;        // K-steps per tap
   int ksteps;     // total K-steps
@@ -109,8 +111,12 @@ __global__ __launch_bounds__(BM * NWN, 2) void igemm_mfma_kernel(KParams p) {
   const int lrow = tid >> 3;
   const int lc = pc ^ ((lrow >> 1) & 7);
   const int Wg = (GEOM == ADN_GEMM_S2) ? Wl : Ws;
-  const int ktot = (GEOM == ADN_GEMM_S2 ? 16 : 4) * Cin;
-  const int ntaps = GEOM == ADN_GEMM_S2 ? 16 : 4;
+  const int ks = p.ks, kpad = p.ks >> 1;                     // S1: kernel side and padding
+  const int ntaps = GEOM == ADN_GEMM_S2 ? 16 : (GEOM == ADN_GEMM_T2 ? 4 : ks * ks);
+  const int ktot = p.wstride;
+  // the descriptor base is shifted back so that every tap offset is >= 0: one row + one pixel for the
+  // k4 geometries, kpad rows + kpad pixels for the same-grid S1 geometry
+  const int bshift = (GEOM == ADN_GEMM_S1) ? kpad * (Ws + 1) : (Wg + 1);
 
   unsigned roff0[APASS], roff1[APASS], amask[APASS];
 #pragma unroll
@@ -130,10 +136,16 @@ __global__ __launch_bounds__(BM * NWN, 2) void igemm_mfma_kernel(KParams p) {
         const int iy = 2 * y - 1 + (t >> 2), ix = 2 * x - 1 + (t & 3);
         if ((unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl) mask |= 1u << t;
       }
-    } else {
+    } else if constexpr (GEOM == ADN_GEMM_T2) {
       pix = (b * Hs + y) * Ws + x;                            // tap (ty,tx) adds dy*Ws + dx
       for (int t = 0; t < 4; ++t) {
         const int iy = y + adn_t2_dy(ph, t >> 1), ix = x + adn_t2_dy(pw, t & 1);
+        if ((unsigned)iy < (unsigned)Hs && (unsigned)ix < (unsigned)Ws) mask |= 1u << t;
+      }
+    } else {
+      pix = (b * Hs + y) * Ws + x;                            // tap (ky,kx) adds (ky-kpad)*Ws + (kx-kpad)
+      for (int t = 0; t < ntaps; ++t) {
+        const int iy = y + t / ks - kpad, ix = x + t % ks - kpad;
         if ((unsigned)iy < (unsigned)Hs && (unsigned)ix < (unsigned)Ws) mask |= 1u << t;
       }
     }
@@ -150,9 +162,9 @@ __global__ __launch_bounds__(BM * NWN, 2) void igemm_mfma_kernel(KParams p) {
 
   typedef __attribute__((address_space(3))) void* lptr_t;
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(reinterpret_cast<const char*>(p.in0) - (int64_t)(Wg + 1) * p.C0 * ESZ), 0, 0x7ffffff0, 0x00020000);
+      (void*)(reinterpret_cast<const char*>(p.in0) - (int64_t)bshift * p.C0 * ESZ), 0, 0x7ffffff0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(reinterpret_cast<const char*>(p.C1 ? p.in1 : p.in0) - (int64_t)(Wg + 1) * p.C1 * ESZ), 0, 0x7ffffff0,
+      (void*)(reinterpret_cast<const char*>(p.C1 ? p.in1 : p.in0) - (int64_t)bshift * p.C1 * ESZ), 0, 0x7ffffff0,
       0x00020000);
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(reinterpret_cast<const char*>(p.w) + (GEOM == ADN_GEMM_T2 ? (int64_t)phase * p.N * ktot * ESZ : 0)), 0,
@@ -174,7 +186,8 @@ __global__ __launch_bounds__(BM * NWN, 2) void igemm_mfma_kernel(KParams p) {
       const int coff = second ? c0 - p.C0 : c0;
       int shift;
       if constexpr (GEOM == ADN_GEMM_S2) shift = (tap >> 2) * Wl + (tap & 3);
-      else shift = (adn_t2_dy(ph, tap >> 1) + 1) * Ws + (adn_t2_dy(pw, tap & 1) + 1);
+      else if constexpr (GEOM == ADN_GEMM_T2) shift = (adn_t2_dy(ph, tap >> 1) + 1) * Ws + (adn_t2_dy(pw, tap & 1) + 1);
+      else shift = (tap / ks) * Ws + tap % ks;
       const int soff = (shift * Cs + coff) * ESZ + lc * 0;
       const unsigned lane_c = (unsigned)(lc * EPC * ESZ);
 #pragma unroll
@@ -198,7 +211,8 @@ __global__ __launch_bounds__(BM * NWN, 2) void igemm_mfma_kernel(KParams p) {
       const int c = k0 - tap * Cin;
       int shift;
       if constexpr (GEOM == ADN_GEMM_S2) shift = (tap >> 2) * Wl + (tap & 3);
-      else shift = (adn_t2_dy(ph, tap >> 1) + 1) * Ws + (adn_t2_dy(pw, tap & 1) + 1);
+      else if constexpr (GEOM == ADN_GEMM_T2) shift = (adn_t2_dy(ph, tap >> 1) + 1) * Ws + (adn_t2_dy(pw, tap & 1) + 1);
+      else shift = (tap / ks) * Ws + tap % ks;
       const unsigned lane_off = (unsigned)((shift * Cin + c) * ESZ);
 #pragma unroll
       for (int j = 0; j < APASS; ++j) {
@@ -285,7 +299,7 @@ __global__ __launch_bounds__(BM * NWN, 2) void igemm_mfma_kernel(KParams p) {
   int epi = p.epi;
   AdnEpiSeg sg;
   int nl;
-  int64_t mout_total = (GEOM == ADN_GEMM_S2) ? (int64_t)p.Msmall : (int64_t)p.Msmall * 4;
+  int64_t mout_total = (GEOM == ADN_GEMM_T2) ? (int64_t)p.Msmall * 4 : (int64_t)p.Msmall;
   if (p.nsplit > 1) {
     epi = ADN_EPI_RAW;
     sg = p.seg[0];
@@ -312,7 +326,7 @@ __global__ __launch_bounds__(BM * NWN, 2) void igemm_mfma_kernel(KParams p) {
     const int m = tile_m * BM + row;
     if (m < p.Msmall) {
       int64_t op;
-      if constexpr (GEOM == ADN_GEMM_S2) {
+      if constexpr (GEOM != ADN_GEMM_T2) {
         op = m;
       } else {
         const int b = m / (Hs * Ws);
@@ -375,7 +389,7 @@ template <typename T, int GEOM>
 __global__ __launch_bounds__(256) void igemm_direct_kernel(KParams p) {
   const int Hs = p.Hs, Ws = p.Ws, Hl = 2 * Hs, Wl = 2 * Ws;
   const int Cin = p.C0 + p.C1;
-  const int64_t mout = (GEOM == ADN_GEMM_S2) ? (int64_t)p.Msmall : (int64_t)p.Msmall * 4;
+  const int64_t mout = (GEOM == ADN_GEMM_T2) ? (int64_t)p.Msmall * 4 : (int64_t)p.Msmall;
   const int64_t total = mout * p.N;
   const T* in0 = reinterpret_cast<const T*>(p.in0);
   const T* in1 = reinterpret_cast<const T*>(p.in1);
@@ -392,7 +406,21 @@ __global__ __launch_bounds__(256) void igemm_direct_kernel(KParams p) {
         const int iy = 2 * oy - 1 + (tap >> 2), ix = 2 * ox - 1 + (tap & 3);
         if ((unsigned)iy >= (unsigned)Hl || (unsigned)ix >= (unsigned)Wl) continue;
         const int64_t pix = ((int64_t)b * Hl + iy) * Wl + ix;
-        const T* wr = w + ((int64_t)n * 16 + tap) * Cin;
+        const T* wr = w + (int64_t)n * p.wstride + tap * Cin;
+        for (int c = 0; c < p.C0; ++c) acc += ElemTraits<T>::load(in0 + pix * p.C0 + c) * ElemTraits<T>::load(wr + c);
+        for (int c = 0; c < p.C1; ++c)
+          acc += ElemTraits<T>::load(in1 + pix * p.C1 + c) * ElemTraits<T>::load(wr + p.C0 + c);
+      }
+    } else if constexpr (GEOM == ADN_GEMM_S1) {
+      const int b = (int)(op / (Hs * Ws));
+      const int rem = (int)(op - (int64_t)b * (Hs * Ws));
+      const int oy = rem / Ws, ox = rem - oy * Ws;
+      const int ks = p.ks, kpad = p.ks >> 1;
+      for (int tap = 0; tap < ks * ks; ++tap) {
+        const int iy = oy + tap / ks - kpad, ix = ox + tap % ks - kpad;
+        if ((unsigned)iy >= (unsigned)Hs || (unsigned)ix >= (unsigned)Ws) continue;
+        const int64_t pix = ((int64_t)b * Hs + iy) * Ws + ix;
+        const T* wr = w + (int64_t)n * p.wstride + tap * Cin;
         for (int c = 0; c < p.C0; ++c) acc += ElemTraits<T>::load(in0 + pix * p.C0 + c) * ElemTraits<T>::load(wr + c);
         for (int c = 0; c < p.C1; ++c)
           acc += ElemTraits<T>::load(in1 + pix * p.C1 + c) * ElemTraits<T>::load(wr + p.C0 + c);
@@ -407,7 +435,7 @@ __global__ __launch_bounds__(256) void igemm_direct_kernel(KParams p) {
         const int iy = i + adn_t2_dy(ph, t >> 1), ix = jx + adn_t2_dy(pw, t & 1);
         if ((unsigned)iy >= (unsigned)Hs || (unsigned)ix >= (unsigned)Ws) continue;
         const int64_t pix = ((int64_t)b * Hs + iy) * Ws + ix;
-        const T* wr = w + (((int64_t)phase * p.N + n) * 4 + t) * Cin;
+        const T* wr = w + ((int64_t)phase * p.N + n) * p.wstride + t * Cin;
         for (int c = 0; c < p.C0; ++c) acc += ElemTraits<T>::load(in0 + pix * p.C0 + c) * ElemTraits<T>::load(wr + c);
         for (int c = 0; c < p.C1; ++c)
           acc += ElemTraits<T>::load(in1 + pix * p.C1 + c) * ElemTraits<T>::load(wr + p.C0 + c);
@@ -457,6 +485,7 @@ inline int reduce_rows(int64_t mout, int N) {
 struct Plan {
   bool mfma;
   bool wide;
+  int wstride;
   int rb;
   int bm;
   int bn;
@@ -475,11 +504,13 @@ bool make_plan(const AdnIgemmDesc* d, Plan* pl) {
   const int64_t msmall = (int64_t)d->B * d->Hs * d->Ws;
   pl->phases = d->geom == ADN_GEMM_T2 ? 4 : 1;
   pl->mout = msmall * pl->phases;
-  const int taps = d->geom == ADN_GEMM_S2 ? 16 : 4;
+  const int taps = d->geom == ADN_GEMM_S2 ? 16 : (d->geom == ADN_GEMM_T2 ? 4 : d->ks * d->ks);
+  pl->wstride = (int)(adn_cdiv((int64_t)taps * Cin, bk) * bk);
   const int epc = 16 / esz;
   // wide: every K-step lies inside one tap of one source; narrow: single source, several taps per K-step
   pl->wide = (d->C0 % bk == 0) && (d->C1 % bk == 0);
-  const bool narrow_ok = (d->C1 == 0) && (d->C0 % epc == 0) && ((taps * Cin) % bk == 0);
+  // (S1 weights are packed with rows zero-padded to the K-step, so taps*Cin need not divide; S2/T2 packs are not)
+  const bool narrow_ok = (d->C1 == 0) && (d->C0 % epc == 0) && (d->geom == ADN_GEMM_S1 || (taps * Cin) % bk == 0);
   const bool aligned = (pl->wide || narrow_ok) && (d->N % 64 == 0) && (d->seg[0].channels % 64 == 0) &&
                        (d->seg[1].channels % 64 == 0);
   pl->mfma = aligned;
@@ -503,7 +534,7 @@ bool make_plan(const AdnIgemmDesc* d, Plan* pl) {
   pl->tiles_m = (int)adn_cdiv(msmall, pl->bm);
   pl->tiles_n = d->N / pl->bn;
   pl->kpt = 0;
-  pl->ksteps = taps * Cin / bk;
+  pl->ksteps = pl->wstride / bk;
   const int64_t tiles = (int64_t)pl->tiles_m * pl->tiles_n * pl->phases;
   int ns = 1;
   if (tiles < 256) {
@@ -569,6 +600,8 @@ int run(const AdnIgemmDesc* d, const Plan& pl, hipStream_t st) {
   kp.C0 = d->C0;
   kp.C1 = d->C1;
   kp.N = d->N;
+  kp.ks = d->geom == ADN_GEMM_S1 ? d->ks : 0;
+  kp.wstride = pl.wstride;
   kp.Msmall = d->B * d->Hs * d->Ws;
   kp.kpt = pl.kpt;
   kp.ksteps = pl.ksteps;
@@ -581,7 +614,8 @@ int run(const AdnIgemmDesc* d, const Plan& pl, hipStream_t st) {
   kp.slab = reinterpret_cast<float*>(d->workspace);
   if (pl.mfma) {
     if (d->geom == ADN_GEMM_S2) dispatch_mfma<T, ADN_GEMM_S2>(kp, pl, st);
-    else dispatch_mfma<T, ADN_GEMM_T2>(kp, pl, st);
+    else if (d->geom == ADN_GEMM_T2) dispatch_mfma<T, ADN_GEMM_T2>(kp, pl, st);
+    else dispatch_mfma<T, ADN_GEMM_S1>(kp, pl, st);
     ADN_CHECK_LAUNCH();
     if (pl.nsplit > 1) {
       hipLaunchKernelGGL((igemm_reduce_kernel<T>),
@@ -595,8 +629,10 @@ int run(const AdnIgemmDesc* d, const Plan& pl, hipStream_t st) {
     if (blocks > 65536) blocks = 65536;
     if (d->geom == ADN_GEMM_S2)
       hipLaunchKernelGGL((igemm_direct_kernel<T, ADN_GEMM_S2>), dim3((unsigned)blocks), dim3(256), 0, st, kp);
-    else
+    else if (d->geom == ADN_GEMM_T2)
       hipLaunchKernelGGL((igemm_direct_kernel<T, ADN_GEMM_T2>), dim3((unsigned)blocks), dim3(256), 0, st, kp);
+    else
+      hipLaunchKernelGGL((igemm_direct_kernel<T, ADN_GEMM_S1>), dim3((unsigned)blocks), dim3(256), 0, st, kp);
     ADN_CHECK_LAUNCH();
     kp.nsplit = 1;
     hipLaunchKernelGGL((igemm_reduce_kernel<T>),
@@ -610,11 +646,14 @@ int run(const AdnIgemmDesc* d, const Plan& pl, hipStream_t st) {
 int validate(const AdnIgemmDesc* d) {
   ADN_CHECK_ARG(d != nullptr, "adn_igemm: null descriptor");
   ADN_CHECK_ARG(d->dtype == ADN_F32 || d->dtype == ADN_BF16, "adn_igemm: bad dtype %d", d->dtype);
-  ADN_CHECK_ARG(d->geom == ADN_GEMM_S2 || d->geom == ADN_GEMM_T2, "adn_igemm: bad geom %d", d->geom);
+  ADN_CHECK_ARG(d->geom == ADN_GEMM_S2 || d->geom == ADN_GEMM_T2 || d->geom == ADN_GEMM_S1, "adn_igemm: bad geom %d",
+                d->geom);
+  ADN_CHECK_ARG(d->geom != ADN_GEMM_S1 || d->ks == 1 || d->ks == 3, "adn_igemm: S1 kernel side must be 1 or 3 (got %d)",
+                d->ks);
   ADN_CHECK_ARG(d->B > 0 && d->Hs > 0 && d->Ws > 0, "adn_igemm: bad shape B=%d Hs=%d Ws=%d", d->B, d->Hs, d->Ws);
   ADN_CHECK_ARG(d->C0 > 0 && d->C1 >= 0 && d->N > 0, "adn_igemm: bad channels C0=%d C1=%d N=%d", d->C0, d->C1, d->N);
   ADN_CHECK_ARG(d->in0 && d->w && (d->C1 == 0 || d->in1), "adn_igemm: null operand");
-  ADN_CHECK_ARG(d->epi >= ADN_EPI_RAW && d->epi <= ADN_EPI_FINAL, "adn_igemm: bad epilogue %d", d->epi);
+  ADN_CHECK_ARG(d->epi >= ADN_EPI_RAW && d->epi <= ADN_EPI_ADD, "adn_igemm: bad epilogue %d", d->epi);
   ADN_CHECK_ARG(d->seg[0].channels + d->seg[1].channels == d->N && d->seg[0].channels > 0 && d->seg[1].channels >= 0,
                 "adn_igemm: segment channels %d+%d != N=%d", d->seg[0].channels, d->seg[1].channels, d->N);
   for (int s = 0; s < 2; ++s) {
@@ -630,6 +669,10 @@ int validate(const AdnIgemmDesc* d) {
   // 32-bit index safety of the per-tensor element counts
   const int64_t big = (int64_t)d->B * d->Hs * d->Ws * 4;
   ADN_CHECK_ARG(big * (d->C0 + d->C1) < (1ll << 40) && big < (1ll << 31), "adn_igemm: tensor too large");
+  // the MFMA loader addresses each gathered source through a 2 GiB buffer descriptor with 32-bit byte offsets
+  const int64_t gpix = (int64_t)d->B * d->Hs * d->Ws * (d->geom == ADN_GEMM_S2 ? 4 : 1);
+  ADN_CHECK_ARG(gpix * (d->C0 > d->C1 ? d->C0 : d->C1) * (d->dtype == ADN_BF16 ? 2 : 4) < 0x7ff00000ll,
+                "adn_igemm: a gathered source exceeds 2 GiB (B=%d %dx%d C=%d/%d)", d->B, d->Hs, d->Ws, d->C0, d->C1);
   return ADN_OK;
 }
 

@@ -22,7 +22,9 @@ struct WParams {
   int tiles_r, tiles_c;
   float* out;     // dW or slab base
   int64_t out_elems;
-  int c_valid;    // gathered channels actually stored (compact [R][16][c_valid]); == C0+C1 normally
+  int c_valid;    // gathered channels actually stored (compact [R][taps][c_valid]); == C0+C1 normally
+  int geom;       // 0: k4 s2 gather (16 taps, gathered tensor on the 2x grid); ADN_GEMM_S1: ks x ks, same grid
+  int ks;
 };
 
 // 128 zero bytes: LDS-DMA source for rows beyond M / padded taps / the upper half of an R=64 tile
@@ -56,7 +58,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
   const int tile_c = lid % p.tiles_c;
   const int tile_r = (lid / p.tiles_c) % p.tiles_r;
   const int split = lid / ntile;
-  const int Hs = p.Hs, Ws = p.Ws, Hl = 2 * Hs, Wl = 2 * Ws;
+  const int Hs = p.Hs, Ws = p.Ws;
+  const bool s1 = p.geom == ADN_GEMM_S1;
+  const int Hl = s1 ? Hs : 2 * Hs, Wl = s1 ? Ws : 2 * Ws;      // grid of the gathered tensor
+  const int kside = s1 ? p.ks : 4, kpad = s1 ? (p.ks >> 1) : 1, gstr = s1 ? 1 : 2;
+  const int ntap = kside * kside;
+  const bool has_pad = !s1 || p.ks == 3;
   const int C = p.C0 + p.C1;
 
   // LDS-DMA staging (global_load_lds_dwordx4): wave w writes 1 KiB = RPP/4 consecutive tile rows per pass,
@@ -73,6 +80,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
   bool r_ok[NV];
   const T* gsrc[NV];
   int Csrc[NV], ky[NV], kx[NV];
+  bool col_ok[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     const int row = prow0 + RPP * v;
@@ -89,8 +97,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
     const int gcol = tile_c * 128 + lc * EPC;
     const int tap = gcol / C;
     const int cch = gcol - tap * C;
-    ky[v] = tap >> 2;
-    kx[v] = tap & 3;
+    col_ok[v] = tap < ntap;            // the last column tile may be partial (9*C is not a multiple of 128)
+    ky[v] = tap / kside;
+    kx[v] = tap - ky[v] * kside;
     if (cch < p.C0) {
       gsrc[v] = reinterpret_cast<const T*>(p.gath0) + cch;
       Csrc[v] = p.C0;
@@ -124,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
     const char* pb = reinterpret_cast<const char*>(psecond ? p.plain1 : p.plain0);
     const bool gsecond = (C >= 128) && ((tile_c * 128) % C) >= p.C0;
     Cs_u = gsecond ? p.C1 : p.C0;
-    const char* gb = reinterpret_cast<const char*>(gsecond ? p.gath1 : p.gath0) - (int64_t)(Wl + 1) * Cs_u * ESZ;
+    const char* gb = reinterpret_cast<const char*>(gsecond ? p.gath1 : p.gath0) - (int64_t)kpad * (Wl + 1) * Cs_u * ESZ;
     rsp = __builtin_amdgcn_make_buffer_rsrc((void*)pb, 0, 0x7ffffff0, 0x00020000);
     rsg = __builtin_amdgcn_make_buffer_rsrc((void*)gb, 0, 0x7ffffff0, 0x00020000);
     const bool rows_in_line = Ws >= BKP;          // a step stays inside one image row
@@ -142,14 +151,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
       const int tap = gcol / C;
       const int cch = gcol - tap * C - (gsecond ? p.C0 : 0);
       const int jx = r & (Ws - 1);
-      const int L = rows_in_line ? 2 * r : 4 * r - 2 * jx;
+      // linear index of the gathered pixel at tap (kpad,kpad): s2: 4m - 2j, s1: m  (scalar part + lane part)
+      const int L = s1 ? r : (rows_in_line ? 2 * r : 4 * r - 2 * jx);
       gvoff[k] = (unsigned)(((L + ky[v] * Wl + kx[v]) * Cs_u + cch) * ESZ);
       const int a = r >> lgWs;                    // image row inside the step (0 when rows_in_line)
-      m_y0[k] = (ky[v] == 0) && (rows_in_line || a == 0);
-      m_y1[k] = (ky[v] == 3) && (rows_in_line || a == q - 1);
-      m_x0[k] = rows_in_line && (kx[v] == 0) && (r == 0);
-      m_x1[k] = rows_in_line && (kx[v] == 3) && (r == BKP - 1);
-      m_c[k] = !rows_in_line && (((kx[v] == 0) && jx == 0) || ((kx[v] == 3) && jx == Ws - 1));
+      const int klast = kside - 1;
+      m_y0[k] = has_pad && (ky[v] == 0) && (rows_in_line || a == 0);
+      m_y1[k] = has_pad && (ky[v] == klast) && (rows_in_line || a == q - 1);
+      m_x0[k] = has_pad && rows_in_line && (kx[v] == 0) && (r == 0);
+      m_x1[k] = has_pad && rows_in_line && (kx[v] == klast) && (r == BKP - 1);
+      m_c[k] = !col_ok[v] ||
+               (has_pad && !rows_in_line && (((kx[v] == 0) && jx == 0) || ((kx[v] == klast) && jx == Ws - 1)));
     }
   }
 
@@ -165,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
       const bool top = si == 0, bot = si == Hs - q;
       const bool left = rows_in_line && sj == 0, right = rows_in_line && sj == Ws - BKP;
       const int psoff = m0 * Rs_u * ESZ;
-      const int gsoff = (4 * m0 - 2 * sj) * Cs_u * ESZ;
+      const int gsoff = (s1 ? m0 : 4 * m0 - 2 * sj) * Cs_u * ESZ;
 #pragma unroll
       for (int k = 0; k < PASSES; ++k) {
         const bool inval = m_c[k] || (top && m_y0[k]) || (bot && m_y1[k]) || (left && m_x0[k]) || (right && m_x1[k]);
@@ -186,8 +198,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
           const int rem = m - b * (Hs * Ws);
           const int i = rem / Ws;
           const int j = rem - i * Ws;
-          const int iy = 2 * i - 1 + ky[v], ix = 2 * j - 1 + kx[v];
-          if ((unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl)
+          const int iy = gstr * i - kpad + ky[v], ix = gstr * j - kpad + kx[v];
+          if (col_ok[v] && (unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl)
             gg = gsrc[v] + (((int64_t)b * Hl + iy) * Wl + ix) * Csrc[v];
         }
         __builtin_amdgcn_global_load_lds((gptr_t)pp, (lptr_t)(pdst + k * (RPP * ROWB)), 16, 0, 0);
@@ -287,11 +299,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
   const int r0 = tid >> 5;    // 8 rows per pass
   const int R = p.R0 + p.R1;
   if (p.c_valid == C) {
-    const int64_t ldo = (int64_t)16 * C;
+    const int64_t ldo = (int64_t)ntap * C;
+    const bool cok = tile_c * 128 + cq * 4 < ntap * C;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       const int row = r0 + 8 * k;
-      if (tile_r * 128 + row < R) {
+      if (cok && tile_r * 128 + row < R) {
         const f32x4_t v = *reinterpret_cast<const f32x4_t*>(ct + row * LDC + cq * 4);
         *reinterpret_cast<f32x4_t*>(out + (int64_t)(tile_r * 128 + row) * ldo + tile_c * 128 + cq * 4) = v;
       }
@@ -304,8 +317,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
       for (int e = 0; e < 4; ++e) {
         const int gc = tile_c * 128 + cq * 4 + e;
         const int tp = gc / C, cc = gc - tp * C;
-        if (cc < p.c_valid)
-          out[((int64_t)(tile_r * 128 + row) * 16 + tp) * p.c_valid + cc] = ct[row * LDC + cq * 4 + e];
+        if (tp < ntap && cc < p.c_valid)
+          out[((int64_t)(tile_r * 128 + row) * ntap + tp) * p.c_valid + cc] = ct[row * LDC + cq * 4 + e];
       }
     }
   }
@@ -315,17 +328,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
 // generic path: one thread per (output element, split)
 template <typename T>
 __global__ __launch_bounds__(256) void wgrad_direct_kernel(WParams p, int pix_per_split) {
-  const int Hs = p.Hs, Ws = p.Ws, Hl = 2 * Hs, Wl = 2 * Ws;
-  const int C = p.C0 + p.C1;
+  const int Hs = p.Hs, Ws = p.Ws;
+  const bool s1 = p.geom == ADN_GEMM_S1;
+  const int Hl = s1 ? Hs : 2 * Hs, Wl = s1 ? Ws : 2 * Ws;
+  const int kside = s1 ? p.ks : 4, kpad = s1 ? (p.ks >> 1) : 1, gstr = s1 ? 1 : 2;
+  const int ntap = kside * kside;
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= p.out_elems) return;
   const int split = blockIdx.y;
   const int cv = p.c_valid;
   const int c = (int)(e % cv);
-  const int tap = (int)((e / cv) % 16);
-  const int r = (int)(e / ((int64_t)16 * cv));
-  (void)C;
-  const int ky = tap >> 2, kx = tap & 3;
+  const int tap = (int)((e / cv) % ntap);
+  const int r = (int)(e / ((int64_t)ntap * cv));
+  const int ky = tap / kside, kx = tap - ky * kside;
   const T* ps = r < p.R0 ? reinterpret_cast<const T*>(p.plain0) + r : reinterpret_cast<const T*>(p.plain1) + (r - p.R0);
   const int Rs = r < p.R0 ? p.R0 : p.R1;
   const T* gs = c < p.C0 ? reinterpret_cast<const T*>(p.gath0) + c : reinterpret_cast<const T*>(p.gath1) + (c - p.C0);
@@ -338,7 +353,7 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(WParams p, int pix_pe
     const int b = m / (Hs * Ws);
     const int rem = m - b * (Hs * Ws);
     const int i = rem / Ws, j = rem - i * Ws;
-    const int iy = 2 * i - 1 + ky, ix = 2 * j - 1 + kx;
+    const int iy = gstr * i - kpad + ky, ix = gstr * j - kpad + kx;
     if ((unsigned)iy >= (unsigned)Hl || (unsigned)ix >= (unsigned)Wl) continue;
     const int64_t pix = ((int64_t)b * Hl + iy) * Wl + ix;
     acc += ElemTraits<T>::load(ps + (int64_t)m * Rs) * ElemTraits<T>::load(gs + pix * Cs);
@@ -381,23 +396,25 @@ void make_wplan(const AdnWgradDesc* d, WPlan* pl) {
   const int R = d->R0 + d->R1, C = d->C0 + d->C1;
   const int64_t msmall = (int64_t)d->B * d->Hs * d->Ws;
   const int cv = d->c_valid > 0 ? d->c_valid : C;
-  pl->out_elems = (int64_t)R * 16 * cv;
+  const int ntap = d->geom == ADN_GEMM_S1 ? d->ks * d->ks : 16;
+  pl->out_elems = (int64_t)R * ntap * cv;
   const int epc = d->dtype == ADN_BF16 ? 8 : 4;
   // sources are selected per 16-byte chunk, so a tile may straddle the two plain / gathered sources
-  const bool aligned = (R % 64 == 0) && (d->R0 % epc == 0) && ((16 * C) % 128 == 0) && (C % epc == 0) &&
-                       (d->C0 % epc == 0) && (C >= 128 ? (C % 128 == 0) : (128 % C == 0));
+  const bool aligned = (R % 64 == 0) && (d->R0 % epc == 0) && (C % epc == 0) && (d->C0 % epc == 0) &&
+                       (C >= 128 ? (C % 128 == 0) : (128 % C == 0));
   pl->mfma = aligned;
   pl->fast = false;
   if (aligned) {
     const int bkp = d->dtype == ADN_BF16 ? 64 : 32;
+    const int64_t esz = d->dtype == ADN_BF16 ? 2 : 4;
     auto pow2 = [](int x) { return x > 0 && (x & (x - 1)) == 0; };
     pl->fast = pow2(d->Hs) && pow2(d->Ws) && d->Hs * d->Ws >= bkp && (d->R1 == 0 || d->R0 % 128 == 0) &&
                (d->C1 == 0 || (d->C0 % 128 == 0 && C % 128 == 0)) &&
-               msmall * 4 * (d->C0 > d->C1 ? d->C0 : d->C1) * 4 < (1ll << 31) &&
-               msmall * (d->R0 > d->R1 ? d->R0 : d->R1) * 4 < (1ll << 31);     // 32-bit scalar byte offsets
+               msmall * (d->geom == ADN_GEMM_S1 ? 1 : 4) * (d->C0 > d->C1 ? d->C0 : d->C1) * esz < (1ll << 31) &&
+               msmall * (d->R0 > d->R1 ? d->R0 : d->R1) * esz < (1ll << 31);     // 32-bit scalar byte offsets
     pl->steps = (int)adn_cdiv(msmall, bkp);
     pl->tiles_r = (int)adn_cdiv(R, 128);
-    pl->tiles_c = 16 * C / 128;
+    pl->tiles_c = (int)adn_cdiv((int64_t)ntap * C, 128);
     const int64_t tiles = (int64_t)pl->tiles_r * pl->tiles_c;
     int ns = (int)adn_cdiv(512, tiles);
     const int max_by_steps = pl->steps / 4 > 0 ? pl->steps / 4 : 1;
@@ -427,6 +444,8 @@ int wvalidate(const AdnWgradDesc* d) {
   ADN_CHECK_ARG((d->R1 == 0 || d->plain1) && (d->C1 == 0 || d->gath1), "adn_wgrad: null second source");
   ADN_CHECK_ARG((int64_t)d->B * d->Hs * d->Ws * 4 < (1ll << 31), "adn_wgrad: tensor too large");
   ADN_CHECK_ARG(d->c_valid >= 0 && d->c_valid <= d->C0 + d->C1, "adn_wgrad: bad c_valid %d", d->c_valid);
+  ADN_CHECK_ARG(d->geom == 0 || (d->geom == ADN_GEMM_S1 && (d->ks == 1 || d->ks == 3)), "adn_wgrad: bad geom/ks %d/%d",
+                d->geom, d->ks);
   return ADN_OK;
 }
 
@@ -440,6 +459,8 @@ int wrun(const AdnWgradDesc* d, const WPlan& pl, hipStream_t st) {
   p.out = pl.nsplit > 1 ? reinterpret_cast<float*>(d->workspace) : d->dw;
   p.out_elems = pl.out_elems;
   p.c_valid = d->c_valid > 0 ? d->c_valid : d->C0 + d->C1;
+  p.geom = d->geom;
+  p.ks = d->ks;
   if (pl.mfma) {
     constexpr int BKP = sizeof(T) == 2 ? 64 : 32;
     constexpr int stage = 4 * BKP * 128 * (int)sizeof(T);

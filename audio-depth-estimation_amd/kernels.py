@@ -10,7 +10,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (ADN_BF16, ADN_F32, EPI_ACT, EPI_BWD, EPI_FINAL, EPI_RAW, EPI_Z_STATS, GEMM_S2, GEMM_T2,
+from ._lib import (ADN_BF16, ADN_F32, EPI_ACT, EPI_ADD, EPI_BWD, EPI_FINAL, EPI_RAW, EPI_Z_STATS, GEMM_S1, GEMM_S2, GEMM_T2,
                    AdnEpiSeg, AdnIgemmDesc, AdnWgradDesc, ptr)
 
 __all__ = ['dtype_code', 'Seg', 'igemm', 'igemm_query', 'wgrad', 'wgrad_workspace_bytes', 'pack_weights',
@@ -78,8 +78,9 @@ class Seg:
         s.final_act = int(self.final_act)
 
 
-def _igemm_desc(dtype, geom, B, Hs, Ws, in0, in1, w, N, epi, segs, workspace=None):
+def _igemm_desc(dtype, geom, B, Hs, Ws, in0, in1, w, N, epi, segs, workspace=None, ks=0):
     d = AdnIgemmDesc()
+    d.ks = ks
     d.dtype, d.geom, d.B, d.Hs, d.Ws = dtype_code(dtype), geom, B, Hs, Ws
     d.C0 = in0.shape[-1]
     d.C1 = in1.shape[-1] if in1 is not None else 0
@@ -95,9 +96,10 @@ def _igemm_desc(dtype, geom, B, Hs, Ws, in0, in1, w, N, epi, segs, workspace=Non
     return d
 
 
-def igemm_query(dtype, geom, B, Hs, Ws, C0, C1, N, seg_channels):
+def igemm_query(dtype, geom, B, Hs, Ws, C0, C1, N, seg_channels, ks=0):
     """(num stats partial rows, workspace bytes) for a shape, without touching the GPU."""
     d = AdnIgemmDesc()
+    d.ks = ks
     d.dtype, d.geom, d.B, d.Hs, d.Ws, d.C0, d.C1, d.N = dtype_code(dtype), geom, B, Hs, Ws, C0, C1, N
     d.in0 = d.w = 1
     d.in1 = 1 if C1 else None
@@ -114,21 +116,23 @@ def igemm_query(dtype, geom, B, Hs, Ws, C0, C1, N, seg_channels):
     return p, wsb
 
 
-def igemm(dtype, geom, B, Hs, Ws, in0, in1, w, N, epi, segs, workspace=None, algo_c=None):
+def igemm(dtype, geom, B, Hs, Ws, in0, in1, w, N, epi, segs, workspace=None, algo_c=None, ks=0):
     """algo_c: real (unpadded) gathered channel count, only used for the algorithmic FLOP count."""
-    d = _igemm_desc(dtype, geom, B, Hs, Ws, in0, in1, w, N, epi, segs, workspace)
+    d = _igemm_desc(dtype, geom, B, Hs, Ws, in0, in1, w, N, epi, segs, workspace, ks)
     ev = _prof_begin()
     _lib.call('adn_igemm', C.byref(d), _stream())
-    # algorithmic FLOPs 2*M_out*N*K, K = taps*Cin  (S2: 16 taps on B*Hs*Ws pixels; T2: 4 taps on 4x the pixels)
-    flops = 2.0 * B * Hs * Ws * N * 16 * (algo_c if algo_c else d.C0 + d.C1)
+    # algorithmic FLOPs 2*M_out*N*K, K = taps*Cin  (S2: 16 taps on B*Hs*Ws pixels; T2: 4 taps on 4x the pixels;
+    # S1: ks*ks taps on B*Hs*Ws pixels)
+    flops = 2.0 * B * Hs * Ws * N * (ks * ks if geom == GEMM_S1 else 16) * (algo_c if algo_c else d.C0 + d.C1)
     _lib.annotate(label='igemm', flops=flops)
     if ev is not None:
         _prof_end(ev, 'igemm', flops)
 
 
-def _wgrad_desc(dtype, B, Hs, Ws, plain0, plain1, gath0, gath1, dw, workspace, c_valid=0):
+def _wgrad_desc(dtype, B, Hs, Ws, plain0, plain1, gath0, gath1, dw, workspace, c_valid=0, ks=0):
     d = AdnWgradDesc()
     d.c_valid = c_valid
+    d.geom, d.ks = (GEMM_S1, ks) if ks else (0, 0)
     d.dtype, d.B, d.Hs, d.Ws = dtype_code(dtype), B, Hs, Ws
     _dev(plain0, plain1, gath0, gath1, dw, workspace)
     d.plain0, d.plain1 = ptr(plain0), ptr(plain1)
@@ -143,9 +147,10 @@ def _wgrad_desc(dtype, B, Hs, Ws, plain0, plain1, gath0, gath1, dw, workspace, c
     return d
 
 
-def wgrad_workspace_bytes(dtype, B, Hs, Ws, R0, R1, C0, C1, c_valid=0):
+def wgrad_workspace_bytes(dtype, B, Hs, Ws, R0, R1, C0, C1, c_valid=0, ks=0):
     d = AdnWgradDesc()
     d.c_valid = c_valid
+    d.geom, d.ks = (GEMM_S1, ks) if ks else (0, 0)
     d.dtype, d.B, d.Hs, d.Ws, d.R0, d.R1, d.C0, d.C1 = dtype_code(dtype), B, Hs, Ws, R0, R1, C0, C1
     d.plain0 = d.gath0 = d.dw = 1
     d.plain1 = 1 if R1 else None
@@ -157,11 +162,12 @@ def wgrad_workspace_bytes(dtype, B, Hs, Ws, R0, R1, C0, C1, c_valid=0):
     return n
 
 
-def wgrad(dtype, B, Hs, Ws, plain0, plain1, gath0, gath1, dw, workspace=None, c_valid=0):
-    d = _wgrad_desc(dtype, B, Hs, Ws, plain0, plain1, gath0, gath1, dw, workspace, c_valid)
+def wgrad(dtype, B, Hs, Ws, plain0, plain1, gath0, gath1, dw, workspace=None, c_valid=0, ks=0):
+    """ks=0: the k4 s2 p1 pair (gathered tensor on the 2x grid); ks in {1,3}: stride-1 ks x ks conv (same grid)."""
+    d = _wgrad_desc(dtype, B, Hs, Ws, plain0, plain1, gath0, gath1, dw, workspace, c_valid, ks)
     ev = _prof_begin()
     _lib.call('adn_wgrad', C.byref(d), _stream())
-    flops = 2.0 * B * Hs * Ws * (d.R0 + d.R1) * 16 * (c_valid if c_valid else d.C0 + d.C1)
+    flops = 2.0 * B * Hs * Ws * (d.R0 + d.R1) * (ks * ks if ks else 16) * (c_valid if c_valid else d.C0 + d.C1)
     _lib.annotate(label='wgrad', flops=flops)
     if ev is not None:
         _prof_end(ev, 'wgrad', flops)
@@ -172,6 +178,26 @@ def pack_weights(master, X, Y, dtype, s2_out=None, t2_out=None, y_pad=None):
     _dev(master, s2_out, t2_out)
     _lib.call('adn_pack_weights', ptr(master), X, Y, Y if y_pad is None else y_pad, dtype_code(dtype), ptr(s2_out),
               ptr(t2_out), _stream())
+
+
+def s1_row_stride(dtype, taps, cin):
+    """Elements per packed S1 weight row: taps*cin rounded up to the 128-byte K-step of the GEMM."""
+    bk = 128 // (2 if dtype == torch.bfloat16 else 4)
+    return -(-taps * cin // bk) * bk
+
+
+def pack_rows(master, X, taps, Y, out, y_pad=None):
+    """master f32 [X][taps][Y] -> out [X][row_stride] = [X][taps][y_pad] + zero tail (S1 forward operand)."""
+    _dev(master, out)
+    _lib.call('adn_pack_rows', ptr(master), X, taps, Y, Y if y_pad is None else y_pad, out.shape[-1],
+              dtype_code(out.dtype), ptr(out), _stream())
+
+
+def pack_transpose_taps(master, X, taps, Y, out, flip=True):
+    """master f32 [X][taps][Y] -> out [Y][row_stride], out[y][t'*X+x] = master[x][t][y] (S1 dgrad operand)."""
+    _dev(master, out)
+    _lib.call('adn_pack_transpose_taps', ptr(master), X, taps, Y, int(flip), out.shape[-1], dtype_code(out.dtype),
+              ptr(out), _stream())
 
 
 def nchw_to_nhwc(src, dst):
@@ -300,3 +326,81 @@ def resize_bilinear(src, S, antialias, out):
     _dev(src, out)
     planes, H, W = src.shape
     _lib.call('adn_resize_bilinear', ptr(src), planes, H, W, S, int(antialias), ptr(out), _stream())
+
+
+# ---- DoubleConv U-Net family (csrc/dcnet.hip) -------------------------------------------------------
+def maxpool2_fwd(src, dst):
+    """src [B,H,W,C] -> dst [B,H//2,W//2,C] (nn.MaxPool2d(2))."""
+    B, H, W, Cc = src.shape
+    _dev(src, dst)
+    _lib.call('adn_maxpool2_fwd', ptr(src), ptr(dst), B, H, W, Cc, dtype_code(src.dtype), _stream())
+
+
+def maxpool2_bwd(gdst, y, gsrc, accumulate):
+    B, H, W, Cc = y.shape
+    _dev(gdst, y, gsrc)
+    _lib.call('adn_maxpool2_bwd', ptr(gdst), ptr(y), ptr(gsrc), B, H, W, Cc, int(bool(accumulate)),
+              dtype_code(y.dtype), _stream())
+
+
+def upsample2x_fwd(src, dst):
+    """Bilinear x2 (align_corners=True) of src [B,Hi,Wi,C], zero padded into dst [B,Ho,Wo,C]."""
+    B, Hi, Wi, Cc = src.shape
+    _dev(src, dst)
+    _lib.call('adn_upsample2x_fwd', ptr(src), ptr(dst), B, Hi, Wi, dst.shape[1], dst.shape[2], Cc,
+              dtype_code(src.dtype), _stream())
+
+
+def upsample2x_bwd(gdst, gsrc, accumulate=False):
+    B, Hi, Wi, Cc = gsrc.shape
+    _dev(gdst, gsrc)
+    _lib.call('adn_upsample2x_bwd', ptr(gdst), ptr(gsrc), B, Hi, Wi, gdst.shape[1], gdst.shape[2], Cc,
+              int(bool(accumulate)), dtype_code(gsrc.dtype), _stream())
+
+
+def relu_bwd_stats_num_partials(pixels, Cc):
+    return _lib.load().adn_relu_bwd_stats_num_partials(pixels, Cc)
+
+
+def relu_bwd_stats(g, y, z, mean, istd, pixels, Cc, partials):
+    _dev(g, y, z, mean, istd, partials)
+    _lib.call('adn_relu_bwd_stats', ptr(g), ptr(y), ptr(z), ptr(mean), ptr(istd), pixels, Cc, dtype_code(g.dtype),
+              ptr(partials), _stream())
+
+
+def head1x1_fwd(x, w, bias, act, max_depth, zpre, out):
+    """x [..., C] NHWC, w f32 [C], bias f32 [1] or None -> zpre/out f32 [pixels]."""
+    Cc = x.shape[-1]
+    _dev(x, w, bias, zpre, out)
+    _lib.call('adn_head1x1_fwd', ptr(x), ptr(w), ptr(bias), x.numel() // Cc, Cc, dtype_code(x.dtype), act,
+              float(max_depth), ptr(zpre), ptr(out), _stream())
+
+
+def head1x1_bwd_workspace_bytes(pixels, Cc):
+    return _lib.load().adn_head1x1_bwd_workspace_bytes(pixels, Cc)
+
+
+def head1x1_bwd(gout, zpre, x, w, act, max_depth, gx, dw, db, workspace):
+    Cc = x.shape[-1]
+    _dev(gout, zpre, x, w, gx, dw, db, workspace)
+    _lib.call('adn_head1x1_bwd', ptr(gout), ptr(zpre), ptr(x), ptr(w), x.numel() // Cc, Cc, dtype_code(x.dtype), act,
+              float(max_depth), ptr(gx), ptr(dw), ptr(db), ptr(workspace),
+              workspace.numel() * workspace.element_size(), _stream())
+
+
+def l1tv_workspace_bytes(n):
+    return _lib.load().adn_l1tv_workspace_bytes(n)
+
+
+def l1tv_stats(pred, gt, stats, workspace):
+    B, H, W = pred.shape[0], pred.shape[-2], pred.shape[-1]
+    _dev(pred, gt, stats, workspace)
+    _lib.call('adn_l1tv_stats', ptr(pred), ptr(gt), B, H, W, ptr(stats), ptr(workspace),
+              workspace.numel() * workspace.element_size(), _stream())
+
+
+def l1tv_finish(pred, gt, stats, replicas, lambda_l1, lambda_smooth, loss_out, grad):
+    B, H, W = pred.shape[0], pred.shape[-2], pred.shape[-1]
+    _dev(pred, gt, stats, loss_out, grad)
+    _lib.call('adn_l1tv_finish', ptr(pred), ptr(gt), B, H, W, ptr(stats), int(replicas), float(lambda_l1),
+              float(lambda_smooth), ptr(loss_out), ptr(grad), _stream())

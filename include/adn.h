@@ -18,7 +18,8 @@
  *     accumulation, BatchNorm statistics, loss and optimizer state are always f32 (or f64 for
  *     final reductions).
  *   - "packed weights": S2 form [N][16][C] (tap = kh*4+kw), T2 form [4][N][4][C]
- *     (phase = (oy&1)*2+(ox&1), tap = ty*2+tx); see adn_pack_weights.
+ *     (phase = (oy&1)*2+(ox&1), tap = ty*2+tx), S1 form [N][ks*ks][C] with every row zero-padded to a
+ *     multiple of 128 bytes; see adn_pack_weights / adn_pack_transpose_taps.
  */
 #ifndef ADN_H_
 #define ADN_H_
@@ -39,18 +40,22 @@ enum { ADN_F32 = 0, ADN_BF16 = 1 };
 /* gather geometry of an implicit GEMM */
 enum {
   ADN_GEMM_S2 = 0, /* k4 s2 p1 conv forward / k4 s2 p1 transposed-conv dgrad: out = small grid */
-  ADN_GEMM_T2 = 1  /* k4 s2 p1 transposed-conv forward / conv dgrad: out = large grid, 4 phases */
+  ADN_GEMM_T2 = 1, /* k4 s2 p1 transposed-conv forward / conv dgrad: out = large grid, 4 phases */
+  ADN_GEMM_S1 = 2  /* ks x ks, stride 1, pad ks/2 conv (ks = 1 or 3) forward and dgrad: out = in grid
+                      (nn.Conv2d(k3,p1) of DoubleConv, binaural_attention_model.py:30,33; 1x1 convs :96-101,:245) */
 };
 
 /* epilogue of an implicit GEMM */
 enum {
   ADN_EPI_RAW = 0,   /* out0 = v as f32 (debug / building block)                                 */
-  ADN_EPI_Z_STATS,   /* out0 = v (dtype), partial sums of v and v*v per channel (train-mode BN)  */
+  ADN_EPI_Z_STATS,   /* z = v (+bias[n]); out0 = z (dtype), partial sums of z and z*z per channel
+                        (train-mode BN)                                                          */
   ADN_EPI_ACT,       /* y = v*scale[n]+shift[n] (+bias[n]); out0 = leaky(y,slope) if out0,
                         out1 = relu(y) if out1   (layers without BN, eval-mode BN)               */
   ADN_EPI_BWD,       /* g = v * (ref>0 ? 1 : slope) (+ out0 if accumulate); out0 = g;
                         optional partial sums of g and g*xhat, xhat=(z-mean)*istd                */
-  ADN_EPI_FINAL      /* out0(f32) = final_act(v + bias[n]); final_act: 0 relu, 1 sigmoid         */
+  ADN_EPI_FINAL,     /* out0(f32) = final_act(v + bias[n]); final_act: 0 relu, 1 sigmoid         */
+  ADN_EPI_ADD        /* out0 (dtype) = v (+ out0 if accumulate): plain input-gradient accumulation */
 };
 
 /* One channel segment of the output (virtual concat: the output channels [0,N) may be split
@@ -86,6 +91,8 @@ typedef struct {
   AdnEpiSeg seg[2];
   void* workspace;    /* split-K / generic-path scratch (f32), adn_igemm_workspace_bytes()       */
   int64_t workspace_bytes;
+  int32_t ks;         /* ADN_GEMM_S1: kernel side, 1 or 3 (Hs, Ws = the common grid)              */
+  int32_t reserved;
 } AdnIgemmDesc;
 
 const char* adn_last_error(void);
@@ -114,6 +121,9 @@ typedef struct {
   void* workspace; int64_t workspace_bytes;
   int32_t c_valid;            /* 0 = all gathered channels; else only c < c_valid are stored (the edge
                                  layers run with their 2 / 1 real channels zero-padded to one 16-byte chunk) */
+  int32_t geom;               /* 0: k4 s2 p1 pair (16 taps, gathered tensor on the 2x grid);
+                                 ADN_GEMM_S1: ks x ks stride-1 conv (ks*ks taps, same grid), dw [R][ks*ks][c] */
+  int32_t ks;
 } AdnWgradDesc;
 int64_t adn_wgrad_workspace_bytes(const AdnWgradDesc* d);
 int adn_wgrad(const AdnWgradDesc* d, void* stream);
@@ -124,6 +134,54 @@ int adn_wgrad(const AdnWgradDesc* d, void* stream);
  *   t2_out: [4][Y][4][X] in dtype (phase split)                        or NULL */
 int adn_pack_weights(const float* master, int32_t X, int32_t Y, int32_t y_pad, int32_t dtype,
                      void* s2_out, void* t2_out, void* stream);
+
+/* Stride-1 (S1) operand packs from a master [X][taps][Y] f32 (= channels_last memory of an [X,Y,k,k] Conv2d
+ * weight).  Rows of both outputs are zero padded to row_stride elements (a multiple of the 128-byte K-step).
+ *   adn_pack_rows:           out [X][taps][y_pad] + zero tail     (forward operand; y_pad pads thin inputs)
+ *   adn_pack_transpose_taps: out [Y][taps'][X], taps' flipped     (input-gradient operand of the same conv) */
+int adn_pack_rows(const float* master, int32_t X, int32_t taps, int32_t Y, int32_t y_pad,
+                  int32_t row_stride, int32_t dtype, void* out, void* stream);
+int adn_pack_transpose_taps(const float* master, int32_t X, int32_t taps, int32_t Y, int32_t flip,
+                            int32_t row_stride, int32_t dtype, void* out, void* stream);
+
+/* ---- DoubleConv U-Net family (DoubleConv / Down / Up: binaural_attention_model.py:22-78, identical copies
+ * rgb_depth_model.py:21-77, adabins_distillation_model.py:27-82).  NHWC activations in dtype. ---- */
+/* nn.MaxPool2d(2): src [B][H][W][C] -> dst [B][H/2][W/2][C]; backward routes each window's gradient to its
+ * first maximum (torch's tie rule), gsrc = (accumulate ? gsrc : 0) + routed. */
+int adn_maxpool2_fwd(const void* src, void* dst, int32_t B, int32_t H, int32_t W, int32_t C,
+                     int32_t dtype, void* stream);
+int adn_maxpool2_bwd(const void* gdst, const void* y, void* gsrc, int32_t B, int32_t H, int32_t W,
+                     int32_t C, int32_t accumulate, int32_t dtype, void* stream);
+/* nn.Upsample(scale_factor=2, bilinear, align_corners=True) + F.pad to the skip's Ho x Wo
+ * (pad top/left = diff // 2).  src [B][Hi][Wi][C] -> dst [B][Ho][Wo][C]; backward is a gather. */
+int adn_upsample2x_fwd(const void* src, void* dst, int32_t B, int32_t Hi, int32_t Wi, int32_t Ho,
+                       int32_t Wo, int32_t C, int32_t dtype, void* stream);
+int adn_upsample2x_bwd(const void* gdst, void* gsrc, int32_t B, int32_t Hi, int32_t Wi, int32_t Ho,
+                       int32_t Wo, int32_t C, int32_t accumulate, int32_t dtype, void* stream);
+/* ReLU + BatchNorm backward, first pass, for a gradient that did not come through a GEMM epilogue:
+ * g <- g * (y > 0) in place and partial sums [P][2][C] of g and g * xhat for adn_bn_bwd_finalize
+ * (P = adn_relu_bwd_stats_num_partials). */
+int64_t adn_relu_bwd_stats_num_partials(int64_t pixels, int32_t C);
+int adn_relu_bwd_stats(void* g, const void* y, const void* z, const float* mean, const float* istd,
+                       int64_t pixels, int32_t C, int32_t dtype, float* partials, void* stream);
+/* 1x1 conv to one channel + output activation (rgb_depth_model.py:195-209: outc, clamp(0, max_depth);
+ * binaural_attention_model.py:330-337: sigmoid(outc) * max_depth, clamp).  act 0 clamp, 1 sigmoid.
+ * zpre/out f32 [pixels]; backward writes gx (dtype [pixels][C]), dw [C], db [1]. */
+int adn_head1x1_fwd(const void* x, const float* w, const float* bias, int64_t pixels, int32_t C,
+                    int32_t dtype, int32_t act, float max_depth, float* zpre, float* out, void* stream);
+int64_t adn_head1x1_bwd_workspace_bytes(int64_t pixels, int32_t C);
+int adn_head1x1_bwd(const float* gout, const float* zpre, const void* x, const float* w, int64_t pixels,
+                    int32_t C, int32_t dtype, int32_t act, float max_depth, void* gx, float* dw,
+                    float* db, void* workspace, int64_t workspace_bytes, void* stream);
+/* DepthLoss (train_rgb_depth.py:43-87): lambda_l1 * mean|p-g| + lambda_smooth * (mean|dx p| + mean|dy p|),
+ * unmasked.  stats f64[4] = [sum|p-g|, sum|dx|, sum|dy|, 0]; a data-parallel caller all-reduces stats and
+ * passes replicas = world size (the means are over the global batch). */
+int64_t adn_l1tv_workspace_bytes(int64_t n);
+int adn_l1tv_stats(const float* pred, const float* gt, int32_t B, int32_t H, int32_t W, double* stats,
+                   void* workspace, int64_t workspace_bytes, void* stream);
+int adn_l1tv_finish(const float* pred, const float* gt, int32_t B, int32_t H, int32_t W,
+                    const double* stats, int32_t replicas, float lambda_l1, float lambda_smooth,
+                    float* loss_out, float* grad, void* stream);
 
 /* NCHW f32 <-> NHWC dtype layout conversion of the network input/output
  * (model(audio) boundary, train.py:642).  dst has c_pad >= C channels, the extra ones zero. */

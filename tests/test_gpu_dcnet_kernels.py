@@ -1,0 +1,349 @@
+"""GPU parity of the DoubleConv-family kernels (S1 implicit GEMM + csrc/dcnet.hip) against torch-CPU fp32.
+
+Reference ops: DoubleConv / Down / Up (/root/reference/models/rgb_depth_model.py:21-77 and the identical copies in
+binaural_attention_model.py:22-78, adabins_distillation_model.py:27-82), the 1x1 depth head + clamp / sigmoid
+(rgb_depth_model.py:195-209, binaural_attention_model.py:330-337) and DepthLoss (train_rgb_depth.py:43-87).
+Tolerances as in test_gpu_kernels.py: inputs are pre-rounded to the storage dtype, the reference is fp32 on the
+same rounded values; f32 outputs <= 2e-5 (f32 path) / 1e-4 (bf16 path) of max|ref|, bf16 outputs <= 6e-3.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def K():
+    from audio_depth_estimation_amd import kernels
+    return kernels
+
+
+def rel_err(a, b):
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def rounded(x, dtype):
+    return x.to(dtype).float()
+
+
+def nhwc(x, dtype):
+    return x.permute(0, 2, 3, 1).contiguous().to(dtype).to(DEV)
+
+
+def from_nhwc(y):
+    return y.float().cpu().permute(0, 3, 1, 2)
+
+
+TOL_F32_OUT = {torch.float32: 2e-5, torch.bfloat16: 1e-4}
+TOL_T_OUT = {torch.float32: 2e-5, torch.bfloat16: 6e-3}
+DTYPES = [torch.float32, torch.bfloat16]
+
+# (B, C0, C1, N, H, W, ks)
+S1_SHAPES = [
+    (2, 64, 0, 128, 16, 16, 3),     # MFMA wide, BN=128
+    (2, 64, 64, 64, 8, 16, 3),      # two gathered sources (virtual concat), non-square
+    (3, 128, 0, 128, 2, 2, 3),      # tiny grid: every tap partly padded; split-K
+    (8, 64, 0, 128, 32, 32, 3),     # fused LDS epilogue
+    (4, 128, 128, 64, 64, 64, 3),   # 256-row tiles
+    (2, 8, 0, 64, 16, 16, 3),       # thin input: narrow loader, K = 72 padded to the K-step
+    (2, 16, 0, 64, 7, 9, 3),        # narrow, odd sizes
+    (2, 6, 0, 10, 5, 5, 3),         # generic direct path
+    (1, 3, 5, 1, 5, 4, 3),          # generic, two sources, one output channel
+    (2, 64, 0, 128, 16, 16, 1),     # 1x1 conv (attention projections / fusion layers)
+    (2, 128, 64, 64, 8, 8, 1),      # 1x1 two sources
+    (2, 6, 0, 10, 5, 5, 1),         # 1x1 generic
+]
+
+
+def s1_operands(w, dtype):
+    """[N, Cin, k, k] parameter -> (forward operand [N][rs], input-gradient operand [Cin][rs']) device tensors."""
+    k = K()
+    N, Cin, ks, _ = w.shape
+    taps = ks * ks
+    master = w.permute(0, 2, 3, 1).contiguous().to(DEV)          # channels_last memory == [N][taps][Cin]
+    fwd = torch.empty(N, k.s1_row_stride(dtype, taps, Cin), dtype=dtype, device=DEV)
+    k.pack_rows(master, N, taps, Cin, fwd)
+    dg = torch.empty(Cin, k.s1_row_stride(dtype, taps, N), dtype=dtype, device=DEV)
+    k.pack_transpose_taps(master, N, taps, Cin, dg, flip=True)
+    return fwd, dg
+
+
+def ws_for(dtype, B, H, W, C0, C1, N, segs, ks):
+    k = K()
+    P, nbytes = k.igemm_query(dtype, k.GEMM_S1, B, H, W, C0, C1, N, segs, ks=ks)
+    return P, torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=DEV)
+
+
+def test_pack_s1_layouts():
+    torch.manual_seed(0)
+    w = torch.randn(6, 10, 3, 3)
+    fwd, dg = s1_operands(w, torch.float32)
+    assert fwd.shape == (6, 96) and dg.shape == (10, 64)
+    np.testing.assert_array_equal(fwd[:, :90].cpu().numpy(), w.permute(0, 2, 3, 1).reshape(6, 90).numpy())
+    assert float(fwd[:, 90:].abs().max()) == 0.0
+    ref = w.flip(2, 3).permute(1, 2, 3, 0).reshape(10, 54)        # [Cin][flipped taps][N]
+    np.testing.assert_array_equal(dg[:, :54].cpu().numpy(), ref.numpy())
+    assert float(dg[:, 54:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', S1_SHAPES)
+def test_conv_forward_s1(dtype, shape):
+    """S1 geometry == nn.Conv2d(k, padding=k//2, bias=False) forward (rgb_depth_model.py:29-33)."""
+    B, C0, C1, N, H, W, ks = shape
+    torch.manual_seed(1)
+    x = rounded(torch.randn(B, C0 + C1, H, W), dtype)
+    w = rounded(torch.randn(N, C0 + C1, ks, ks) * 0.1, dtype)
+    ref = F.conv2d(x, w, padding=ks // 2)
+    fwd, _ = s1_operands(w, dtype)
+    in0 = nhwc(x[:, :C0], dtype)
+    in1 = nhwc(x[:, C0:], dtype) if C1 else None
+    out = torch.empty(B, H, W, N, dtype=torch.float32, device=DEV)
+    _, ws = ws_for(dtype, B, H, W, C0, C1, N, [N], ks)
+    k = K()
+    k.igemm(dtype, k.GEMM_S1, B, H, W, in0, in1, fwd, N, k.EPI_RAW, [k.Seg(N, out0=out)], ws, ks=ks)
+    assert rel_err(from_nhwc(out), ref) <= TOL_F32_OUT[dtype]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', S1_SHAPES)
+def test_conv_z_stats_s1(dtype, shape):
+    """Z_STATS epilogue on the S1 geometry: raw conv output in dtype + per-channel sum / sum of squares."""
+    B, C0, C1, N, H, W, ks = shape
+    torch.manual_seed(2)
+    x = rounded(torch.randn(B, C0 + C1, H, W), dtype)
+    w = rounded(torch.randn(N, C0 + C1, ks, ks) * 0.1, dtype)
+    ref = F.conv2d(x, w, padding=ks // 2)
+    fwd, _ = s1_operands(w, dtype)
+    in0 = nhwc(x[:, :C0], dtype)
+    in1 = nhwc(x[:, C0:], dtype) if C1 else None
+    z = torch.empty(B, H, W, N, dtype=dtype, device=DEV)
+    P, ws = ws_for(dtype, B, H, W, C0, C1, N, [N], ks)
+    part = torch.zeros(P * 2 * N, dtype=torch.float32, device=DEV)
+    k = K()
+    k.igemm(dtype, k.GEMM_S1, B, H, W, in0, in1, fwd, N, k.EPI_Z_STATS, [k.Seg(N, out0=z, partials=part)], ws, ks=ks)
+    assert rel_err(from_nhwc(z), ref) <= TOL_T_OUT[dtype]
+    sums = part.view(P, 2, N).double().sum(0).cpu()
+    zz = from_nhwc(z).double()                                      # statistics are of the STORED values
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    ref1, ref2 = zz.sum((0, 2, 3)), (zz * zz).sum((0, 2, 3))
+    assert float((sums[0] - ref1).abs().max()) <= tol * float(ref1.abs().max() + zz.abs().sum((0, 2, 3)).max() * 1e-3)
+    assert float((sums[1] - ref2).abs().max()) <= tol * float(ref2.abs().max())
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', S1_SHAPES)
+def test_conv_dgrad_s1(dtype, shape):
+    """Input gradient of the stride-1 conv = S1 GEMM of dz with the transposed, tap-flipped operand; the two
+    output segments are the two halves of the virtual concat (EPI_ADD, second call accumulates)."""
+    B, C0, C1, N, H, W, ks = shape
+    torch.manual_seed(3)
+    Cin = C0 + C1
+    w = rounded(torch.randn(N, Cin, ks, ks) * 0.1, dtype)
+    dz = rounded(torch.randn(B, N, H, W), dtype)
+    ref = F.conv_transpose2d(dz, w, padding=ks // 2)               # == grad of conv2d wrt its input
+    _, dg = s1_operands(w, dtype)
+    g0 = torch.empty(B, H, W, C0, dtype=dtype, device=DEV)
+    g1 = torch.empty(B, H, W, C1, dtype=dtype, device=DEV) if C1 else None
+    k = K()
+    segs = [k.Seg(C0, out0=g0)] + ([k.Seg(C1, out0=g1)] if C1 else [])
+    _, ws = ws_for(dtype, B, H, W, N, 0, Cin, [C0, C1] if C1 else [C0], ks)
+    dzd = nhwc(dz, dtype)
+    k.igemm(dtype, k.GEMM_S1, B, H, W, dzd, None, dg, Cin, k.EPI_ADD, segs, ws, ks=ks)
+    got = torch.cat([from_nhwc(g0)] + ([from_nhwc(g1)] if C1 else []), 1)
+    assert rel_err(got, ref) <= TOL_T_OUT[dtype]
+    # accumulate on top of the first result: exactly doubles (up to the storage rounding)
+    for s in segs:
+        s.accumulate = True
+    k.igemm(dtype, k.GEMM_S1, B, H, W, dzd, None, dg, Cin, k.EPI_ADD, segs, ws, ks=ks)
+    got2 = torch.cat([from_nhwc(g0)] + ([from_nhwc(g1)] if C1 else []), 1)
+    assert rel_err(got2, 2 * ref) <= 2 * TOL_T_OUT[dtype]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', S1_SHAPES)
+def test_conv_wgrad_s1(dtype, shape):
+    """Weight gradient of the stride-1 conv: dw[n][tap][c] = sum_pix dz[pix][n] * in[pix + tap][c]."""
+    B, C0, C1, N, H, W, ks = shape
+    torch.manual_seed(4)
+    Cin = C0 + C1
+    x = rounded(torch.randn(B, Cin, H, W), dtype)
+    dz = rounded(torch.randn(B, N, H, W), dtype)
+    wz = torch.zeros(N, Cin, ks, ks, requires_grad=True)
+    F.conv2d(x, wz, padding=ks // 2).backward(dz)
+    ref = wz.grad.permute(0, 2, 3, 1).reshape(N, ks * ks, Cin)
+    k = K()
+    nb = k.wgrad_workspace_bytes(dtype, B, H, W, N, 0, C0, C1, ks=ks)
+    ws = torch.empty(max(nb, 16) // 4, dtype=torch.float32, device=DEV)
+    dw = torch.full((N, ks * ks, Cin), float('nan'), dtype=torch.float32, device=DEV)
+    in0 = nhwc(x[:, :C0], dtype)
+    in1 = nhwc(x[:, C0:], dtype) if C1 else None
+    k.wgrad(dtype, B, H, W, nhwc(dz, dtype), None, in0, in1, dw, ws, ks=ks)
+    assert rel_err(dw, ref) <= TOL_F32_OUT[dtype]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_conv_wgrad_s1_thin_input(dtype):
+    """First layer: 3 real input channels zero-padded to one 16-byte chunk, compact [N][9][3] gradient."""
+    B, N, H, W, Cin = 2, 64, 16, 16, 3
+    torch.manual_seed(5)
+    epc = 8 if dtype == torch.bfloat16 else 4
+    x = rounded(torch.randn(B, Cin, H, W), dtype)
+    dz = rounded(torch.randn(B, N, H, W), dtype)
+    wz = torch.zeros(N, Cin, 3, 3, requires_grad=True)
+    F.conv2d(x, wz, padding=1).backward(dz)
+    ref = wz.grad.permute(0, 2, 3, 1).reshape(N, 9, Cin)
+    xp = torch.zeros(B, epc, H, W)
+    xp[:, :Cin] = x
+    k = K()
+    nb = k.wgrad_workspace_bytes(dtype, B, H, W, N, 0, epc, 0, c_valid=Cin, ks=3)
+    ws = torch.empty(max(nb, 16) // 4, dtype=torch.float32, device=DEV)
+    dw = torch.full((N, 9, Cin), float('nan'), dtype=torch.float32, device=DEV)
+    k.wgrad(dtype, B, H, W, nhwc(dz, dtype), None, nhwc(xp, dtype), None, dw, ws, c_valid=Cin, ks=3)
+    assert rel_err(dw, ref) <= TOL_F32_OUT[dtype]
+    # and the forward of the same layer through the padded operand
+    w = rounded(torch.randn(N, Cin, 3, 3) * 0.1, dtype)
+    master = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    fwd = torch.empty(N, k.s1_row_stride(dtype, 9, epc), dtype=dtype, device=DEV)
+    k.pack_rows(master, N, 9, Cin, fwd, y_pad=epc)
+    out = torch.empty(B, H, W, N, dtype=torch.float32, device=DEV)
+    _, ws2 = ws_for(dtype, B, H, W, epc, 0, N, [N], 3)
+    k.igemm(dtype, k.GEMM_S1, B, H, W, nhwc(xp, dtype), None, fwd, N, k.EPI_RAW, [k.Seg(N, out0=out)], ws2, ks=3)
+    assert rel_err(from_nhwc(out), F.conv2d(x, w, padding=1)) <= TOL_F32_OUT[dtype]
+
+
+# ---------------------------------------------------------------------------------------------------------
+EW_SHAPES = [(2, 16, 8, 12), (2, 64, 16, 16), (1, 5, 7, 9), (3, 8, 2, 2)]      # (B, C, H, W)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', EW_SHAPES)
+def test_maxpool2(dtype, shape):
+    B, C, H, W = shape
+    torch.manual_seed(6)
+    # post-ReLU-like input with many exact ties (zeros, and a coarse grid of positive values)
+    x = rounded((torch.randn(B, C, H, W) * 2).round().clamp(min=0) * 0.5, dtype).requires_grad_(True)
+    y = F.max_pool2d(x, 2)
+    gy = rounded(torch.randn_like(y), dtype)
+    y.backward(gy)
+    k = K()
+    xd = nhwc(x.detach(), dtype)
+    yd = torch.empty(B, H // 2, W // 2, C, dtype=dtype, device=DEV)
+    k.maxpool2_fwd(xd, yd)
+    np.testing.assert_array_equal(from_nhwc(yd).numpy(), y.detach().numpy())
+    gx = torch.full((B, H, W, C), float('nan'), dtype=dtype, device=DEV)
+    k.maxpool2_bwd(nhwc(gy, dtype), xd, gx, accumulate=False)
+    np.testing.assert_array_equal(from_nhwc(gx).numpy(), x.grad.numpy())     # ties resolved like torch
+    base = rounded(torch.randn(B, C, H, W), dtype)
+    gx2 = nhwc(base, dtype)
+    k.maxpool2_bwd(nhwc(gy, dtype), xd, gx2, accumulate=True)
+    assert rel_err(from_nhwc(gx2), base + x.grad) <= TOL_T_OUT[dtype]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(2, 16, 4, 6, 0, 0), (2, 64, 8, 8, 0, 0), (1, 5, 3, 4, 1, 1), (2, 8, 1, 1, 0, 1),
+                                   (2, 8, 16, 16, 0, 0)])
+def test_upsample2x(dtype, shape):
+    """Up: bilinear x2 align_corners=True, then F.pad to the skip size (rgb_depth_model.py:61-75)."""
+    B, C, Hi, Wi, dH, dW = shape
+    Ho, Wo = 2 * Hi + dH, 2 * Wi + dW
+    torch.manual_seed(7)
+    x = rounded(torch.randn(B, C, Hi, Wi), dtype).requires_grad_(True)
+    up = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=True)
+    up = F.pad(up, [dW // 2, dW - dW // 2, dH // 2, dH - dH // 2])
+    g = rounded(torch.randn_like(up), dtype)
+    up.backward(g)
+    k = K()
+    out = torch.full((B, Ho, Wo, C), float('nan'), dtype=dtype, device=DEV)
+    k.upsample2x_fwd(nhwc(x.detach(), dtype), out)
+    assert rel_err(from_nhwc(out), up.detach()) <= TOL_T_OUT[dtype]
+    gx = torch.full((B, Hi, Wi, C), float('nan'), dtype=dtype, device=DEV)
+    k.upsample2x_bwd(nhwc(g, dtype), gx)
+    assert rel_err(from_nhwc(gx), x.grad) <= TOL_T_OUT[dtype]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(2, 64, 16, 16), (4, 128, 32, 32), (2, 5, 7, 9), (1, 8, 3, 3), (2, 512, 4, 4)])
+def test_relu_bwd_stats(dtype, shape):
+    B, C, H, W = shape
+    torch.manual_seed(8)
+    z = rounded(torch.randn(B, C, H, W), dtype)
+    mean, istd = torch.randn(C) * 0.1, torch.rand(C) + 0.5
+    y = rounded(torch.relu((z - mean[None, :, None, None]) * istd[None, :, None, None]), dtype)
+    g = rounded(torch.randn(B, C, H, W), dtype)
+    gm = g * (y > 0)
+    xh = (z - mean[None, :, None, None]) * istd[None, :, None, None]
+    k = K()
+    pixels = B * H * W
+    P = k.relu_bwd_stats_num_partials(pixels, C)
+    part = torch.full((P, 2, C), float('nan'), dtype=torch.float32, device=DEV)
+    gd = nhwc(g, dtype)
+    k.relu_bwd_stats(gd, nhwc(y, dtype), nhwc(z, dtype), mean.to(DEV), istd.to(DEV), pixels, C, part)
+    np.testing.assert_array_equal(from_nhwc(gd).numpy(), gm.numpy())
+    sums = part.double().sum(0).cpu()
+    ref1, ref2 = gm.double().sum((0, 2, 3)), (gm * xh).double().sum((0, 2, 3))
+    scale = float(gm.abs().sum((0, 2, 3)).max())
+    assert float((sums[0] - ref1).abs().max()) <= 1e-5 * scale
+    assert float((sums[1] - ref2).abs().max()) <= 1e-5 * scale * float(xh.abs().max())
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('act', [0, 1])
+@pytest.mark.parametrize('shape', [(2, 64, 16, 16), (2, 8, 5, 7), (1, 5, 4, 4), (2, 256, 4, 4)])
+def test_head1x1(dtype, act, shape):
+    """outc (1x1 -> 1 channel) + clamp(0, max) / sigmoid * max: forward, input grad, weight and bias grads."""
+    B, C, H, W = shape
+    maxd = 30.0
+    torch.manual_seed(9)
+    x = rounded(torch.randn(B, C, H, W), dtype).requires_grad_(True)
+    w = (torch.randn(1, C, 1, 1) * (6.0 if act == 0 else 0.3)).requires_grad_(True)     # act 0: reach both clamps
+    b = torch.tensor([2.0 if act == 0 else 0.1], requires_grad=True)
+    zz = F.conv2d(x, w, b)
+    out = torch.clamp(zz, 0, maxd) if act == 0 else torch.clamp(torch.sigmoid(zz) * maxd, 0, maxd)
+    gout = torch.randn_like(out)
+    out.backward(gout)
+    k = K()
+    pixels = B * H * W
+    xd = nhwc(x.detach(), dtype)
+    wd, bd = w.detach().reshape(C).to(DEV), b.detach().to(DEV)
+    zpre = torch.empty(pixels, dtype=torch.float32, device=DEV)
+    o = torch.empty(pixels, dtype=torch.float32, device=DEV)
+    k.head1x1_fwd(xd, wd, bd, act, maxd, zpre, o)
+    assert rel_err(o.view(B, 1, H, W), out.detach()) <= 1e-5
+    gx = torch.full((B, H, W, C), float('nan'), dtype=dtype, device=DEV)
+    dw = torch.full((C,), float('nan'), dtype=torch.float32, device=DEV)
+    db = torch.full((1,), float('nan'), dtype=torch.float32, device=DEV)
+    ws = torch.empty(k.head1x1_bwd_workspace_bytes(pixels, C) // 4, dtype=torch.float32, device=DEV)
+    k.head1x1_bwd(gout.reshape(-1).to(DEV), zpre, xd, wd, act, maxd, gx, dw, db, ws)
+    assert rel_err(from_nhwc(gx), x.grad) <= TOL_T_OUT[dtype]
+    assert rel_err(dw, w.grad.reshape(C)) <= 2e-5
+    assert rel_err(db, b.grad) <= 2e-5
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 16), (3, 7, 9), (4, 64, 64)])
+@pytest.mark.parametrize('replicas', [1, 2])
+def test_l1tv_loss(shape, replicas):
+    """DepthLoss (train_rgb_depth.py:43-87): value and d loss / d pred, incl. sign(0) = 0 ties."""
+    B, H, W = shape
+    torch.manual_seed(10)
+    pred = (torch.rand(B, 1, H, W) * 8).round().div(2).requires_grad_(True)     # coarse grid: many zero differences
+    gt = (torch.rand(B, 1, H, W) * 8).round().div(2)
+    l1 = F.l1_loss(pred, gt)
+    sm = (pred[:, :, :, :-1] - pred[:, :, :, 1:]).abs().mean() + (pred[:, :, :-1, :] - pred[:, :, 1:, :]).abs().mean()
+    loss = 1.0 * l1 + 0.1 * sm
+    loss.backward()
+    k = K()
+    pd, gd = pred.detach().to(DEV), gt.to(DEV)
+    stats = torch.zeros(4, dtype=torch.float64, device=DEV)
+    ws = torch.empty(k.l1tv_workspace_bytes(B * H * W) // 8, dtype=torch.float64, device=DEV)
+    k.l1tv_stats(pd, gd, stats, ws)
+    stats *= replicas                                           # what the all-reduce over identical replicas gives
+    lo = torch.zeros(1, dtype=torch.float32, device=DEV)
+    grad = torch.full_like(pd, float('nan'))
+    k.l1tv_finish(pd, gd, stats, replicas, 1.0, 0.1, lo, grad)
+    assert abs(float(lo) - float(loss)) <= 1e-6 * abs(float(loss))
+    assert rel_err(grad * replicas, pred.grad) <= 1e-5
