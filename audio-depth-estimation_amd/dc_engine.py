@@ -1,0 +1,410 @@
+"""DoubleConv U-Net family on libadn kernels: an op tape over NHWC activations.
+
+Replaces what PyTorch dispatches for ``model(x)`` / ``loss.backward()`` of the reference's DoubleConv-based
+networks (/root/reference/models/rgb_depth_model.py:80-218, binaural_attention_model.py:155-340): a model
+mirror describes its forward as a list of ops over named activation records; the engine runs the list forward
+and in reverse for the backward pass.  Every op is a handful of libadn launches (C ABI, include/adn.h):
+
+  ConvBNReLU   (Conv2d k3/k1 -> BatchNorm2d -> ReLU)   S1 implicit GEMM with the Z+stats epilogue, BN finalize,
+               one BN+ReLU materialisation pass; backward = [ReLU+BN stats pass |fused into the consumer's dgrad
+               epilogue] -> finalize -> apply -> wgrad -> dgrad (S1 GEMM with the flipped/transposed operand)
+  MaxPool2 / Upsample2x / Head1x1        memory-bound kernels of csrc/dcnet.hip
+
+Data layout in HBM: activations NHWC in the compute dtype (bf16 throughput path, f32 exact path); per
+ConvBNReLU the raw conv output z and the activated y (y feeds the next GEMM through LDS-DMA, z is needed by the
+BN backward); one gradient buffer per activation, written by its consumers in backward order (first writer
+overwrites, later writers accumulate); skip concats are virtual (two base pointers into the consumer GEMM).
+Parameters/gradients: flat f32 buffers (flat.py); gradients become final from the END of the flat buffer
+towards its start because backward visits the ops in reverse parameters() order.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from . import kernels as K
+from .flat import FlatParamEngine
+from ._lib import EPI_ACT, EPI_ADD, EPI_BWD, EPI_Z_STATS, GEMM_S1
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+class Act:
+    """One NHWC activation record: data (+ raw conv output z and BN statistics when produced by ConvBNReLU)."""
+
+    def __init__(self, name, C, H, W, needs_grad=True):
+        self.name, self.C, self.H, self.W = name, C, H, W
+        self.needs_grad = needs_grad
+        self.data = None
+        self.grad = None
+        self.producer = None
+        self.consumers = []
+        self.fused_bwd = False       # sole consumer is a conv: its dgrad epilogue applies the ReLU mask + BN stats
+        self.written = False         # a consumer already wrote .grad in the current backward pass
+        self.z = self.mean = self.istd = self.bpart = None
+        self.bpart_rows = 0
+
+    def alloc(self, B, dtype, dev):
+        self.data = torch.empty(B, self.H, self.W, self.C, dtype=dtype, device=dev)
+        if self.needs_grad:
+            self.grad = torch.empty_like(self.data)
+
+
+class Op:
+    params = ()
+
+    def prepare(self, eng):
+        pass
+
+    def workspace_bytes(self, eng):
+        return 0
+
+
+class ConvBNReLU(Op):
+    """Conv2d(k in {1,3}, padding k//2) [+bias] -> BatchNorm2d -> ReLU over the virtual concat of ``srcs``."""
+
+    def __init__(self, srcs, conv, bn, out):
+        self.srcs, self.conv, self.bn, self.out = list(srcs), conv, bn, out
+        self.ks = conv.kernel_size[0]
+        assert conv.kernel_size in ((1, 1), (3, 3)) and conv.stride == (1, 1) and conv.padding == (self.ks // 2,) * 2
+        assert len(self.srcs) in (1, 2)
+        out.producer = self
+        for s in self.srcs:
+            s.consumers.append(self)
+
+    def prepare(self, eng):
+        T, dev, B = eng.dtype, eng.dev, eng.B
+        o = self.out
+        N = o.C
+        self.N = N
+        self.cin_real = sum(s.C_real if hasattr(s, 'C_real') else s.C for s in self.srcs)
+        self.c0 = self.srcs[0].C
+        self.c1 = self.srcs[1].C if len(self.srcs) > 1 else 0
+        cin = self.c0 + self.c1                       # as the kernels see it (thin inputs are zero padded)
+        taps = self.ks * self.ks
+        w = self.conv.weight
+        assert w.shape[1] == self.cin_real and w.shape[0] == N
+        f32 = dict(dtype=torch.float32, device=dev)
+        # forward operand [N][row stride]: the parameter memory itself when rows need no padding
+        rs = K.s1_row_stride(T, taps, cin)
+        self.fwd_is_view = (rs == taps * self.cin_real)
+        if self.fwd_is_view:
+            src = eng.flat_p if T == torch.float32 else eng.flat_w16
+            self.w_fwd = eng._flat_slice(src, w).view(N, rs)
+        else:
+            self.w_fwd = torch.empty(N, rs, dtype=T, device=dev)
+        # input-gradient operand [Cin][row stride'] (flipped taps, transposed channels)
+        self.need_dgrad = any(s.needs_grad for s in self.srcs)
+        self.w_dg = torch.empty(cin, K.s1_row_stride(T, taps, N), dtype=T, device=dev) if self.need_dgrad else None
+        o.z = torch.empty_like(o.data)
+        o.mean, o.istd = torch.empty(N, **f32), torch.empty(N, **f32)
+        self.scale, self.shift = torch.empty(N, **f32), torch.empty(N, **f32)
+        self.coef = torch.empty(2 * N, **f32)
+        H, W = o.H, o.W
+        self.P, ws1 = K.igemm_query(T, GEMM_S1, B, H, W, self.c0, self.c1, N, [N], ks=self.ks)
+        self.part = torch.empty(self.P * 2 * N, **f32)
+        ws2 = 0
+        if self.need_dgrad:
+            segc = [self.c0, self.c1] if self.c1 else [self.c0]
+            pg, ws2 = K.igemm_query(T, GEMM_S1, B, H, W, N, 0, cin, segc, ks=self.ks)
+            for s in self.srcs:
+                if s.fused_bwd:
+                    s.bpart_rows = pg
+                    s.bpart = torch.empty(pg * 2 * s.C, **f32)
+        if not o.fused_bwd and o.needs_grad:
+            o.bpart_rows = K.relu_bwd_stats_num_partials(B * H * W, N)
+            o.bpart = torch.empty(o.bpart_rows * 2 * N, **f32)
+        cv = self.cin_real if self.cin_real != cin else 0
+        ws3 = K.wgrad_workspace_bytes(T, B, H, W, N, 0, self.c0, self.c1, c_valid=cv, ks=self.ks)
+        self.c_valid = cv
+        self._ws = max(ws1, ws2, ws3)
+
+    def workspace_bytes(self, eng):
+        return self._ws
+
+    def pack(self, eng):
+        w = self.conv.weight
+        taps = self.ks * self.ks
+        master = eng._flat_slice(eng.flat_p, w)
+        if not self.fwd_is_view:
+            K.pack_rows(master, self.N, taps, self.cin_real, self.w_fwd, y_pad=self.c0 + self.c1)
+        if self.w_dg is not None:
+            K.pack_transpose_taps(master, self.N, taps, self.cin_real, self.w_dg, flip=True)
+
+    def fwd(self, eng, training):
+        T, B, o = eng.dtype, eng.B, self.out
+        in0 = self.srcs[0].data
+        in1 = self.srcs[1].data if self.c1 else None
+        bn, N = self.bn, self.N
+        pixels = B * o.H * o.W
+        if training:
+            K.igemm(T, GEMM_S1, B, o.H, o.W, in0, in1, self.w_fwd, N, EPI_Z_STATS,
+                    [K.Seg(N, out0=o.z, partials=self.part, bias=self.conv.bias)], eng.workspace,
+                    algo_c=self.cin_real, ks=self.ks)
+            track = bn.track_running_stats and bn.running_mean is not None
+            K.bn_fwd_finalize(self.part, self.P, N, pixels, bn.weight, bn.bias, bn.eps,
+                              BN_MOMENTUM if bn.momentum is None else bn.momentum,
+                              bn.running_mean if track else None, bn.running_var if track else None,
+                              bn.num_batches_tracked if track else None, o.mean, o.istd, self.scale, self.shift)
+            K.bn_act(o.z, pixels, N, self.scale, self.shift, 0.0, None, o.data)
+        else:
+            K.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, self.scale, self.shift)
+            if self.conv.bias is not None:                    # BN(conv + b) = conv * scale + (shift + b * scale)
+                self.shift.addcmul_(self.conv.bias.detach(), self.scale)
+            K.igemm(T, GEMM_S1, B, o.H, o.W, in0, in1, self.w_fwd, N, EPI_ACT,
+                    [K.Seg(N, out1=o.data, scale=self.scale, shift=self.shift)], eng.workspace,
+                    algo_c=self.cin_real, ks=self.ks)
+
+    def bwd(self, eng):
+        T, B, o = eng.dtype, eng.B, self.out
+        N, bn = self.N, self.bn
+        pixels = B * o.H * o.W
+        G = o.grad
+        if not o.fused_bwd:
+            K.relu_bwd_stats(G, o.data, o.z, o.mean, o.istd, pixels, N, o.bpart)
+        K.bn_bwd_finalize(o.bpart, o.bpart_rows, N, pixels, eng._flat_slice(eng.flat_g, bn.weight),
+                          eng._flat_slice(eng.flat_g, bn.bias), self.coef)
+        K.bn_bwd_apply(G, o.z, pixels, N, self.scale, o.mean, o.istd, self.coef)      # G is now d loss / d z
+        eng._mark(bn.weight, bn.bias)
+        if self.conv.bias is not None:
+            # a bias in front of BatchNorm has an identically zero gradient (BN subtracts the batch mean); the
+            # reference accumulates float noise here, we write the exact value
+            eng._flat_slice(eng.flat_g, self.conv.bias).zero_()
+            eng._mark(self.conv.bias)
+        in0 = self.srcs[0].data
+        in1 = self.srcs[1].data if self.c1 else None
+        K.wgrad(T, B, o.H, o.W, G, None, in0, in1, eng._flat_slice(eng.flat_g, self.conv.weight), eng.workspace,
+                c_valid=self.c_valid, ks=self.ks)
+        eng._ready(self.conv.weight)
+        if not self.need_dgrad:
+            return
+        segs, epi = [], EPI_ADD
+        for s in self.srcs:
+            if s.fused_bwd:
+                epi = EPI_BWD
+                segs.append(K.Seg(s.C, out0=s.grad, ref=s.data, slope=0.0, z=s.z, mean=s.mean, istd=s.istd,
+                                  partials=s.bpart, accumulate=s.written))
+            else:
+                segs.append(K.Seg(s.C, out0=s.grad if s.needs_grad else eng.scratch_like(s), accumulate=s.written))
+            s.written = True
+        K.igemm(T, GEMM_S1, B, o.H, o.W, G, None, self.w_dg, self.c0 + self.c1, epi, segs, eng.workspace, ks=self.ks)
+
+
+class MaxPool2(Op):
+    def __init__(self, src, out):
+        self.src, self.out = src, out
+        out.producer = self
+        src.consumers.append(self)
+
+    def fwd(self, eng, training):
+        K.maxpool2_fwd(self.src.data, self.out.data)
+
+    def bwd(self, eng):
+        K.maxpool2_bwd(self.out.grad, self.src.data, self.src.grad, accumulate=self.src.written)
+        self.src.written = True
+
+
+class Upsample2x(Op):
+    """nn.Upsample(scale_factor=2, bilinear, align_corners=True) + F.pad to out's H x W."""
+
+    def __init__(self, src, out):
+        self.src, self.out = src, out
+        out.producer = self
+        src.consumers.append(self)
+
+    def fwd(self, eng, training):
+        K.upsample2x_fwd(self.src.data, self.out.data)
+
+    def bwd(self, eng):
+        K.upsample2x_bwd(self.out.grad, self.src.grad, accumulate=self.src.written)
+        self.src.written = True
+
+
+class Head1x1(Op):
+    """Conv2d(C, 1, 1) + clamp(0, max_depth) (act 0) or sigmoid * max_depth + clamp (act 1); f32 [B,1,H,W] out."""
+
+    def __init__(self, src, conv, act, max_depth):
+        self.src, self.conv, self.act, self.max_depth = src, conv, act, float(max_depth)
+        assert conv.kernel_size == (1, 1) and conv.out_channels == 1
+        src.consumers.append(self)
+
+    def prepare(self, eng):
+        s = self.src
+        pixels = eng.B * s.H * s.W
+        f32 = dict(dtype=torch.float32, device=eng.dev)
+        self.zpre = torch.empty(pixels, **f32)
+        self.result = torch.empty(eng.B, 1, s.H, s.W, **f32)
+        self._ws = K.head1x1_bwd_workspace_bytes(pixels, s.C)
+
+    def workspace_bytes(self, eng):
+        return self._ws
+
+    def fwd(self, eng, training):
+        w = eng._flat_slice(eng.flat_p, self.conv.weight)
+        K.head1x1_fwd(self.src.data, w, self.conv.bias, self.act, self.max_depth, self.zpre, self.result)
+
+    def bwd_head(self, eng, gout):
+        s = self.src
+        assert not s.written
+        w = eng._flat_slice(eng.flat_p, self.conv.weight)
+        db = eng._flat_slice(eng.flat_g, self.conv.bias) if self.conv.bias is not None else None
+        K.head1x1_bwd(gout, self.zpre, s.data, w, self.act, self.max_depth, s.grad,
+                      eng._flat_slice(eng.flat_g, self.conv.weight), db, eng.workspace)
+        s.written = True
+        eng._mark(self.conv.bias)
+        eng._ready(self.conv.weight)
+
+
+class DCEngine(FlatParamEngine):
+    """Runs a DoubleConv-family module through libadn.  ``build(engine, B, C, H, W)`` (supplied by the model
+    mirror) returns (input Act, ops, head): the forward op list in execution order and the output head."""
+
+    def __init__(self, module, build, compute_dtype=torch.bfloat16, model_name='model'):
+        self.module = module
+        self._build = build
+        self.dtype = compute_dtype
+        self.model_name = model_name
+        self.depth_norm = False
+        self._init_flat()
+        self.ops = []
+        self._scratch = {}
+
+    def scratch_like(self, act):
+        """Throw-away gradient target for a source that needs no gradient but shares a dgrad GEMM."""
+        key = (act.C, act.H, act.W)
+        if key not in self._scratch:
+            self._scratch[key] = torch.empty(self.B, act.H, act.W, act.C, dtype=self.dtype, device=self.dev)
+        return self._scratch[key]
+
+    def _prepare(self, x):
+        if not self._bound():
+            self.bind_parameters()
+        B, Cin, H, W = x.shape
+        key = (B, Cin, H, W, x.device)
+        if key == self._shape_key:
+            return
+        self.B, self.dev = B, x.device
+        self._scratch = {}
+        epc = 8 if self.dtype == torch.bfloat16 else 4
+        self.epc = epc
+        self.inp, self.ops, self.head = self._build(self, B, Cin, H, W)
+        acts = {}
+        for op in self.ops:
+            for a in list(getattr(op, 'srcs', [])) + [getattr(op, 'src', None), getattr(op, 'out', None)]:
+                if a is not None:
+                    acts[id(a)] = a
+        self.acts = list(acts.values())
+        for a in self.acts:
+            prod = a.producer
+            a.fused_bwd = (isinstance(prod, ConvBNReLU) and len(a.consumers) == 1 and
+                           isinstance(a.consumers[0], ConvBNReLU) and len(a.consumers[0].srcs) == 1)
+            a.alloc(B, self.dtype, x.device)
+        ws = 16
+        for op in self.ops + [self.head]:
+            op.prepare(self)
+            ws = max(ws, op.workspace_bytes(self))
+        self.workspace = torch.empty(ws // 4 + 4, dtype=torch.float32, device=x.device)
+        self.weights_dirty = True
+        self._shape_key = key
+
+    def thin_input(self, name, C, H, W):
+        """Network input record: C real channels zero-padded to one 16-byte chunk for the MFMA loader."""
+        cp = (C + self.epc - 1) // self.epc * self.epc
+        a = Act(name, cp, H, W, needs_grad=False)
+        a.C_real = C
+        return a
+
+    def _pack_weights(self):
+        if self.flat_w16 is not None and not self.s2_fresh:
+            _lib.record_py(lambda: self.flat_w16.copy_(self.flat_p))
+        for op in self.ops:
+            if isinstance(op, ConvBNReLU):
+                op.pack(self)
+        self.weights_dirty = False
+        self.s2_fresh = False
+        self._packed_version = self._version_sum()
+
+    def load_input(self, x):
+        K.nchw_to_nhwc(x, self.inp.data)
+
+    def forward(self, x, training):
+        if not x.is_cuda:
+            raise RuntimeError(f'{self.model_name}.forward needs a HIP device tensor (libadn has no CPU path)')
+        x = x.contiguous().float()
+        self._prepare(x)
+        if self.weights_dirty or self._packed_version != self._version_sum():
+            self._pack_weights()
+        self.load_input(x)
+        for op in self.ops:
+            op.fwd(self, training)
+        self.head.fwd(self, training)
+        return self.head.result
+
+    def _mark(self, *params):
+        for p in params:
+            if p is not None:
+                self._final.add(id(p))
+
+    def _ready(self, param):
+        """``param``'s gradient is final: advance the watermark below which flat_g may still change and hand
+        the data-parallel reducer every bucket above it (ops may finish in any order)."""
+        self._final.add(id(param))
+        idx = self._wm
+        while idx > 0 and id(self.param_meta[idx - 1][0]) in self._final:
+            idx -= 1
+        if idx != self._wm:
+            self._wm = idx
+            if self.on_grad_ready is not None:
+                off = self.param_meta[idx][1]
+                _lib.record_py(lambda: self.on_grad_ready(off))
+
+    def backward(self, gout):
+        """gout: d loss / d output, f32 [B,1,H,W].  Fills flat_g (all parameters)."""
+        for a in self.acts:
+            a.written = False
+        self._final = set(id(p) for p, _, _ in self.param_meta if not p.requires_grad)
+        self._wm = len(self.param_meta)
+        gout = gout.contiguous().float()
+        self.head.bwd_head(self, gout)
+        for op in reversed(self.ops):
+            if op.out.needs_grad:
+                op.bwd(self)
+        if self.on_grad_ready is not None:
+            _lib.record_py(lambda: self.on_grad_ready(0))
+
+    def features(self, names):
+        """NCHW f32 copies of named activations (return_features=True of the reference forward)."""
+        res = {}
+        by_name = {a.name: a for a in self.acts}
+        for n in names:
+            a = by_name[n]
+            t = torch.empty(self.B, a.C, a.H, a.W, dtype=torch.float32, device=self.dev)
+            K.nhwc_to_nchw(a.data, t)
+            res[n] = t
+        return res
+
+
+class _DCFunction(torch.autograd.Function):
+    """torch.autograd bridge: parameters are inputs so that loss.backward() reaches them."""
+
+    @staticmethod
+    def forward(ctx, x, engine, training, *params):
+        ctx.engine = engine
+        return engine.forward(x, training).clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        eng = ctx.engine
+        eng.backward(gout)
+        return (None, None, None) + tuple(eng.grad_view(p) for p, _, _ in eng.param_meta)
+
+
+def run_dcnet(engine, x, training):
+    if not engine._bound():
+        engine.bind_parameters()
+    needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p, _, _ in engine.param_meta)
+    if needs_grad and training:
+        return _DCFunction.apply(x, engine, training, *[p for p, _, _ in engine.param_meta])
+    with torch.no_grad():
+        return engine.forward(x, training).clone()

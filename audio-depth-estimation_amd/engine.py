@@ -23,6 +23,7 @@ import torch
 
 from . import _lib
 from . import kernels as K
+from .flat import FlatParamEngine, _align
 from ._lib import EPI_ACT, EPI_BWD, EPI_FINAL, EPI_Z_STATS, GEMM_S2, GEMM_T2
 
 BN_EPS = 1e-5
@@ -35,11 +36,7 @@ class _Level:
     pass
 
 
-def _align(n, a=4):
-    return (n + a - 1) // a * a
-
-
-class UNetEngine:
+class UNetEngine(FlatParamEngine):
     """Runs UnetGenerator.forward/backward through libadn.  One engine per module instance."""
 
     def __init__(self, module, num_downs, depth_norm, compute_dtype=torch.bfloat16):
@@ -49,68 +46,9 @@ class UNetEngine:
         self.dtype = compute_dtype
         self.levels = module._adn_levels()          # list of dicts with layer objects, outermost first
         assert len(self.levels) == num_downs
-        self.flat_p = None
-        self.flat_g = None
-        self.param_meta = []                        # (param, offset, numel)
-        self._shape_key = None
-        self._packed_version = None
-        self.weights_dirty = True
-        self.on_grad_ready = None                   # callback(offset_lo): flat_g[offset_lo:] is final
+        self.model_name = 'UnetGenerator'
+        self._init_flat()
         self._saved = None
-
-    # ------------------------------------------------------------------ parameters
-    def _bound(self):
-        if self.flat_p is None:
-            return False
-        p0, off0, _ = self.param_meta[0]
-        pl, offl, _ = self.param_meta[-1]
-        base = self.flat_p.data_ptr()
-        return p0.data_ptr() == base + 4 * off0 and pl.data_ptr() == base + 4 * offl
-
-    def bind_parameters(self):
-        """(Re)create the flat parameter/gradient buffers and re-point the module's Parameters into them."""
-        params = list(self.module.parameters())
-        dev = params[0].device
-        if dev.type != 'cuda':
-            raise RuntimeError('UnetGenerator runs on libadn HIP kernels only: move the model to a HIP device '
-                               '(define_G(..., gpu_ids=[0]) or .to("cuda")); there is no CPU path')
-        total, meta = 0, []
-        for p in params:
-            meta.append((p, total, p.numel()))
-            total += _align(p.numel())
-        flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
-        flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
-        for p, off, n in meta:
-            view = self._view(flat_p, off, p)
-            view.copy_(p.data)
-            p.data = view
-            p.grad = None
-        self.flat_p, self.flat_g, self.param_meta, self.total = flat_p, flat_g, meta, total
-        # bf16 mirror of the parameters (same offsets): the fused optimizer writes it, the S2 GEMM operands
-        # of the unpadded layers are views into it
-        self.flat_w16 = torch.zeros(total, dtype=torch.bfloat16, device=dev) if self.dtype == torch.bfloat16 else None
-        self.offset = {id(p): off for p, off, _ in meta}
-        self.weights_dirty = True
-        self.s2_fresh = False
-        self._shape_key = None
-
-    @staticmethod
-    def _view(flat, off, p):
-        n = p.numel()
-        if p.dim() == 4:
-            X, Y, kh, kw = p.shape
-            return flat[off:off + n].view(X, kh, kw, Y).permute(0, 3, 1, 2)
-        return flat[off:off + n].view(p.shape)
-
-    def grad_view(self, p):
-        return self._view(self.flat_g, self.offset[id(p)], p)
-
-    def _flat_slice(self, buf, p):
-        off = self.offset[id(p)]
-        return buf[off:off + p.numel()]
-
-    def _version_sum(self):
-        return sum(p._version for p, _, _ in self.param_meta)
 
     def _pack_weights(self):
         """Cast/pack the f32 master weights into the GEMM operand forms.
@@ -420,10 +358,12 @@ class FusedTrainer:
     """One fused training step: forward + masked loss + backward + (all-reduce) + clip + optimizer.
 
     Mirrors the hot loop of /root/reference/train.py:633-693 (and train_binaural_attention.py:394-433 when
-    ``clip_norm`` is None and ``mask_mode`` is 'gt0').  Everything stays on device; ``step`` returns the
+    ``clip_norm`` is None and ``mask_mode`` is 'gt0'; train_rgb_depth.py:355-362 with criterion 'DepthLoss',
+    where l1_weight / silog_weight carry lambda_l1 / lambda_smooth).  ``engine`` is a UNetEngine or a DCEngine
+    (both expose forward / backward / flat_p / flat_g / flat_w16).  Everything stays on device; ``step`` returns the
     loss as a 0-dim device tensor (call .item() to reproduce the reference's per-step host sync).
     """
-    CRIT = {'L1': 0, 'SIlog': 1, 'Combined': 2}
+    CRIT = {'L1': 0, 'SIlog': 1, 'Combined': 2, 'DepthLoss': 3}
     OPT = {'AdamW': 0, 'Adam': 1, 'SGD': 2}
 
     def __init__(self, engine, criterion='Combined', l1_weight=0.5, silog_weight=0.5, silog_lambda=0.5,
@@ -536,11 +476,18 @@ class FusedTrainer:
         gt = gt.contiguous().float()
         if self.gout is None or self.gout.shape != pred.shape:
             self.gout = torch.empty_like(pred)
-        K.loss_stats(pred, gt, self.scale, self.mask_mode, 1e-6, self.stats, self.loss_ws)
-        if self.ddp is not None:      # one global-batch loss, as under DataParallel
-            _lib.record_py(lambda: self.ddp.all_reduce_loss_stats(self.stats))
-        K.loss_finish(pred, gt, self.scale, self.mask_mode, 1e-6, self.stats, self.criterion, self.l1_weight,
-                      self.silog_weight, self.silog_lambda, self.loss, self.gout)
+        if self.criterion == 3:       # DepthLoss: unmasked L1 + total variation (train_rgb_depth.py:43-87)
+            K.l1tv_stats(pred, gt, self.stats, self.loss_ws)
+            if self.ddp is not None:
+                _lib.record_py(lambda: self.ddp.all_reduce_loss_stats(self.stats))
+            K.l1tv_finish(pred, gt, self.stats, self.ddp.world_size if self.ddp is not None else 1, self.l1_weight,
+                          self.silog_weight, self.loss, self.gout)
+        else:
+            K.loss_stats(pred, gt, self.scale, self.mask_mode, 1e-6, self.stats, self.loss_ws)
+            if self.ddp is not None:      # one global-batch loss, as under DataParallel
+                _lib.record_py(lambda: self.ddp.all_reduce_loss_stats(self.stats))
+            K.loss_finish(pred, gt, self.scale, self.mask_mode, 1e-6, self.stats, self.criterion, self.l1_weight,
+                          self.silog_weight, self.silog_lambda, self.loss, self.gout)
         if self.ddp is not None:
             _lib.record_py(self.ddp.begin_backward)
         eng.backward(self.gout)

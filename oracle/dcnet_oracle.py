@@ -1,0 +1,135 @@
+"""CPU restatement of the reference's DoubleConv U-Net family (TEST INFRASTRUCTURE ONLY).
+
+Restates, as *functionals* over a flat ``state_dict`` with the reference's key names (so the same tensors can
+be fed to the reference module, to this oracle and to the HIP engine):
+  * DoubleConv / Down / Up            /root/reference/models/rgb_depth_model.py:21-77 (identical copies in
+                                      binaural_attention_model.py:22-78, adabins_distillation_model.py:27-82)
+  * RGBDepthNet.forward               rgb_depth_model.py:148-218
+  * BinauralCrossAttention.forward    binaural_attention_model.py:106-153
+  * BinauralEncoder / BinauralAttentionDepthNet.forward   binaural_attention_model.py:171-178, 280-340
+  * DepthLoss.forward                 train_rgb_depth.py:43-87 (L1 + 0.1 * total variation, unmasked)
+Backward comes from torch autograd over these functionals (leaf tensors with requires_grad), in float64 when a
+test needs a ground truth that is tighter than fp32.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product path
+(audio-depth-estimation_amd/) never does.
+Pinned by: tests/test_oracle_golden.py against tests/golden/rgb64_bc8.npz and tests/golden/binaural64_bc8.npz
+(generated from the reference by tests/golden/make_golden_dcnet.py).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def _bn(x, sd, key, training, new_stats):
+    w, b = sd[key + '.weight'], sd[key + '.bias']
+    rm, rv = sd[key + '.running_mean'], sd[key + '.running_var']
+    if training:
+        rm2, rv2 = rm.clone(), rv.clone()
+        y = F.batch_norm(x, rm2, rv2, w, b, True, BN_MOMENTUM, BN_EPS)
+        new_stats[key + '.running_mean'] = rm2
+        new_stats[key + '.running_var'] = rv2
+        return y
+    return F.batch_norm(x, rm, rv, w, b, False, BN_MOMENTUM, BN_EPS)
+
+
+def double_conv(sd, prefix, x, training, new_stats):
+    """(conv3x3 no bias -> BN -> ReLU) x 2; ``prefix`` ends in '.double_conv' (rgb_depth_model.py:28-35)."""
+    h = F.conv2d(x, sd[prefix + '.0.weight'], None, padding=1)
+    h = F.relu(_bn(h, sd, prefix + '.1', training, new_stats))
+    h = F.conv2d(h, sd[prefix + '.3.weight'], None, padding=1)
+    return F.relu(_bn(h, sd, prefix + '.4', training, new_stats))
+
+
+def down(sd, prefix, x, training, new_stats):
+    """MaxPool2d(2) -> DoubleConv (rgb_depth_model.py:45-49)."""
+    return double_conv(sd, prefix + '.maxpool_conv.1.double_conv', F.max_pool2d(x, 2), training, new_stats)
+
+
+def up(sd, prefix, x1, x2, training, new_stats):
+    """bilinear x2 (align_corners=True) -> pad to the skip -> cat([skip, up]) -> DoubleConv (:61-77)."""
+    x1 = F.interpolate(x1, scale_factor=2, mode='bilinear', align_corners=True)
+    dy, dx = x2.shape[2] - x1.shape[2], x2.shape[3] - x1.shape[3]
+    x1 = F.pad(x1, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
+    return double_conv(sd, prefix + '.conv.double_conv', torch.cat([x2, x1], 1), training, new_stats)
+
+
+def encoder(sd, prefix, x, training, new_stats):
+    """inc, down1..down4 -> [x1..x5] (rgb_depth_model.py:166-170 / binaural_attention_model.py:171-178)."""
+    feats = [double_conv(sd, prefix + 'inc.double_conv', x, training, new_stats)]
+    for i in range(1, 5):
+        feats.append(down(sd, f'{prefix}down{i}', feats[-1], training, new_stats))
+    return feats
+
+
+def decoder(sd, feats, training, new_stats):
+    """up1..up4 over [x1..x5] -> [d4, d3, d2, d1] (rgb_depth_model.py:184-187)."""
+    d, outs = feats[4], []
+    for i in range(4):
+        d = up(sd, f'up{i + 1}', d, feats[3 - i], training, new_stats)
+        outs.append(d)
+    return outs
+
+
+def rgb_forward(sd, x, max_depth=30.0, training=True, return_features=False):
+    """RGBDepthNet.forward (rgb_depth_model.py:148-218) for output_size == input size.
+    Returns (depth, new_running_stats[, features])."""
+    new_stats = {}
+    feats = encoder(sd, '', x, training, new_stats)
+    ds = decoder(sd, feats, training, new_stats)
+    depth = F.conv2d(ds[3], sd['outc.weight'], sd['outc.bias'])
+    depth = torch.clamp(depth, 0, max_depth)                                  # :209
+    if return_features:
+        f = {f'x{i + 1}': feats[i] for i in range(5)}
+        f.update({'d4': ds[0], 'd3': ds[1], 'd2': ds[2], 'd1': ds[3]})
+        return depth, new_stats, f
+    return depth, new_stats
+
+
+def cross_attention(sd, prefix, left, right):
+    """BinauralCrossAttention.forward (binaural_attention_model.py:106-153): both directions share the
+    query/key/value/out projections; softmax over keys of Q^T K / sqrt(C); residual scaled by gamma."""
+    B, C, H, W = left.shape
+
+    def proj(name, t):
+        return F.conv2d(t, sd[f'{prefix}.{name}.weight'], sd[f'{prefix}.{name}.bias'])
+
+    def attend(q_src, kv_src):
+        q = proj('query', q_src).reshape(B, -1, H * W)
+        k = proj('key', kv_src).reshape(B, -1, H * W)
+        v = proj('value', kv_src).reshape(B, C, H * W)
+        att = torch.softmax(torch.bmm(q.transpose(1, 2), k) / (C ** 0.5), dim=-1)       # [B, HW(q), HW(k)]
+        o = torch.bmm(v, att.transpose(1, 2)).reshape(B, C, H, W)
+        return q_src + sd[prefix + '.gamma'] * proj('out', o)
+
+    return attend(left, right), attend(right, left)
+
+
+def binaural_forward(sd, x, max_depth=30.0, attention_levels=(2, 3, 4, 5), training=True):
+    """BinauralAttentionDepthNet.forward (binaural_attention_model.py:280-340), output_size == input size."""
+    new_stats = {}
+    lf = encoder(sd, 'left_encoder.', x[:, 0:1], training, new_stats)
+    rf = encoder(sd, 'right_encoder.', x[:, 1:2], training, new_stats)
+    fused = []
+    for level in range(1, 6):
+        l, r = lf[level - 1], rf[level - 1]
+        if level in attention_levels:
+            l, r = cross_attention(sd, f'attention_modules.attn_{level}', l, r)
+        p = f'fusion_layers.fusion_{level}'
+        h = F.conv2d(torch.cat([l, r], 1), sd[p + '.0.weight'], sd[p + '.0.bias'])
+        fused.append(F.relu(_bn(h, sd, p + '.1', training, new_stats)))
+    ds = decoder(sd, fused, training, new_stats)
+    depth = torch.sigmoid(F.conv2d(ds[3], sd['outc.0.weight'], sd['outc.0.bias'])) * max_depth
+    return torch.clamp(depth, 0, max_depth), new_stats
+
+
+def depth_loss(pred, target, lambda_l1=1.0, lambda_smooth=0.1):
+    """DepthLoss.forward (train_rgb_depth.py:53-85): unmasked L1 + lambda_smooth * (mean|dx| + mean|dy|)."""
+    l1 = (pred - target).abs().mean()
+    dx = (pred[:, :, :, :-1] - pred[:, :, :, 1:]).abs()
+    dy = (pred[:, :, :-1, :] - pred[:, :, 1:, :]).abs()
+    return lambda_l1 * l1 + lambda_smooth * (dx.mean() + dy.mean())

@@ -1,0 +1,176 @@
+"""GPU parity of the DoubleConv-family networks on libadn (models.rgb_depth_model / dc_engine).
+
+  * against the committed golden vectors produced by the REFERENCE (tests/golden/rgb64_bc8.npz; base_channels=8,
+    so the f32 path runs the generic kernels for C%8 != 0 layers and MFMA elsewhere) -- f32 compute, tolerance:
+    prediction relative L1 <= 1e-4, gradients <= 2e-3 of the per-tensor max, one AdamW step <= 2 % of lr;
+  * against the CPU oracle in float64 at full width (base_channels=64, MFMA kernels): f32 prediction relative
+    L1 <= 1e-5, gradients <= 5e-4 of the tensor max; bf16 (no reference counterpart): prediction relative L1
+    <= 2e-2, gradient cosine >= 0.9 per tensor.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+DEV = 'cuda'
+
+
+def rel_l1(a, b):
+    a, b = a.detach().float().cpu(), torch.as_tensor(b).float()
+    return float((a - b).abs().sum() / (b.abs().sum() + 1e-30))
+
+
+def max_rel(a, b):
+    a, b = a.detach().float().cpu(), torch.as_tensor(b).float()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def _rgb(bc, S, dtype, sd=None, max_depth=30.0):
+    from audio_depth_estimation_amd.models.rgb_depth_model import RGBDepthNet
+    model = RGBDepthNet(base_channels=bc, bilinear=True, output_size=S, max_depth=max_depth)
+    model.compute_dtype = dtype
+    if sd is not None:
+        model.load_state_dict(sd)
+    return model.to(DEV)
+
+
+def _check_sd1(sd_now, z, lr):
+    for k in sd_now:
+        ref = torch.from_numpy(z['sd1/' + k])
+        if ref.dtype == torch.int64:
+            assert int(sd_now[k]) == int(ref), k
+        else:
+            assert float((sd_now[k].cpu() - ref).abs().max()) <= 0.02 * lr + 1e-6 * float(ref.abs().max()), k
+
+
+def test_rgb_golden_reference_parity_f32():
+    from audio_depth_estimation_amd.engine import FusedTrainer
+    z = np.load(os.path.join(GOLDEN, 'rgb64_bc8.npz'))
+    bc, S, B = [int(v) for v in z['meta']]
+    lr, wd, max_depth, l1w, sw = [float(v) for v in z['hyper']]
+    sd0 = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('sd0/')}
+    model = _rgb(bc, S, torch.float32, sd0, max_depth)
+    assert list(model.state_dict().keys()) == list(sd0.keys())
+    image, gt = torch.from_numpy(z['image']).to(DEV), torch.from_numpy(z['gt']).to(DEV)
+
+    model.eval()
+    with torch.no_grad():
+        pe = model(image)
+    assert rel_l1(pe, z['pred_eval']) <= 1e-4
+
+    # --- path 1: torch autograd + torch optimizer driving the engine (train_rgb_depth.py:355-362 semantics)
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=wd)
+    opt.zero_grad()
+    pred, feats = model(image, return_features=True)
+    assert rel_l1(pred, z['pred_train']) <= 1e-4
+    for k in ('x1', 'x5', 'd4', 'd1'):
+        assert rel_l1(feats[k], z['feat/' + k]) <= 1e-4, k
+    loss = l1w * (pred - gt).abs().mean() + sw * ((pred[:, :, :, :-1] - pred[:, :, :, 1:]).abs().mean() +
+                                                  (pred[:, :, :-1, :] - pred[:, :, 1:, :]).abs().mean())
+    assert abs(loss.item() - float(z['loss'])) <= 1e-4 * abs(float(z['loss']))
+    loss.backward()
+    for k, prm in model.named_parameters():
+        assert prm.grad is not None, k
+        assert max_rel(prm.grad, z['grad/' + k]) <= 2e-3, k
+    opt.step()
+    _check_sd1(model.state_dict(), z, lr)
+
+    # --- path 2: fully fused step (DepthLoss + AdamW kernels, no clipping) from the same start point
+    model2 = _rgb(bc, S, torch.float32, sd0, max_depth)
+    model2.train()
+    tr = FusedTrainer(model2.engine(), 'DepthLoss', l1w, sw, optimizer='AdamW', lr=lr, weight_decay=wd,
+                      clip_norm=None)
+    loss2, pred2 = tr.step(image, gt)
+    assert abs(loss2.item() - float(z['loss'])) <= 1e-4 * abs(float(z['loss']))
+    assert max_rel(tr.gout, z['pred_grad']) <= 1e-5
+    _check_sd1(model2.state_dict(), z, lr)
+
+
+def _oracle_step(sd, image, gt, max_depth):
+    from oracle import dcnet_oracle
+    sd = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    pkeys = [k for k, v in sd.items() if v.is_floating_point() and 'running_' not in k]
+    for k in pkeys:
+        sd[k].requires_grad_(True)
+    pred, stats = dcnet_oracle.rgb_forward(sd, image.double(), max_depth, training=True)
+    loss = dcnet_oracle.depth_loss(pred, gt.double())
+    loss.backward()
+    return pred.detach(), loss.item(), {k: sd[k].grad for k in pkeys}, stats
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_rgb_full_width_against_oracle(dtype):
+    """base_channels=64 at 64x64, B=2: every conv runs the MFMA S1 kernels (thin first layer included)."""
+    from audio_depth_estimation_amd.engine import FusedTrainer
+    torch.manual_seed(0)
+    S = 64
+    model = _rgb(64, S, dtype)
+    with torch.no_grad():
+        model.outc.bias.fill_(2.0)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(1234)
+    image = torch.rand(2, 3, S, S, generator=g)
+    gt = 30 * torch.rand(2, 1, S, S, generator=g)
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    pred_ref, loss_ref, grads_ref, stats_ref = _oracle_step(sd, image, gt, 30.0)
+
+    model.train()
+    tr = FusedTrainer(model.engine(), 'DepthLoss', 1.0, 0.1, optimizer='AdamW', lr=1e-4, weight_decay=0.01,
+                      clip_norm=None)
+    eng = model.engine()
+    loss, pred = tr.step(image.to(DEV), gt.to(DEV))
+    f32 = dtype == torch.float32
+    assert rel_l1(pred, pred_ref) <= (1e-5 if f32 else 2e-2)
+    assert abs(loss.item() - loss_ref) <= (1e-5 if f32 else 5e-3) * abs(loss_ref)
+    for k, prm in model.named_parameters():
+        got = eng.grad_view(prm).detach().float().cpu().reshape(-1)
+        ref = grads_ref[k].reshape(-1).float()
+        if f32:
+            assert max_rel(got, ref) <= 5e-4, (k, max_rel(got, ref))
+        else:
+            cos = float(torch.dot(got, ref) / (got.norm() * ref.norm() + 1e-30))
+            assert cos >= 0.9, (k, cos)
+    for k, v in stats_ref.items():
+        got = model.state_dict()[k].cpu()
+        v = v.float()
+        assert float((got - v).abs().max()) <= (1e-5 if f32 else 3e-2) * float(v.abs().max()) + 1e-6, k
+
+
+def test_rgb_graph_and_plan_match_eager():
+    """hipGraph replay and launch-plan replay of the fused RGB step give the eager parameters."""
+    from audio_depth_estimation_amd.engine import FusedTrainer
+    g = torch.Generator().manual_seed(3)
+    image = torch.rand(2, 3, 64, 64, generator=g).to(DEV)
+    gt = (30 * torch.rand(2, 1, 64, 64, generator=g)).to(DEV)
+    finals = []
+    for mode in ('eager', 'graph', 'plan'):
+        torch.manual_seed(0)
+        model = _rgb(32, 64, torch.bfloat16)
+        model.train()
+        tr = FusedTrainer(model.engine(), 'DepthLoss', 1.0, 0.1, optimizer='AdamW', lr=1e-3, weight_decay=0.01,
+                          clip_norm=None)
+        if mode == 'graph':
+            tr.enable_graph(after_steps=2)
+        elif mode == 'plan':
+            tr.enable_launch_plan(after_steps=2)
+        for _ in range(5):
+            loss, _ = tr.step(image, gt)
+        torch.cuda.synchronize()
+        finals.append((float(loss), model.engine().flat_p.detach().clone()))
+    for lossv, flat in finals[1:]:
+        assert abs(lossv - finals[0][0]) <= 1e-6 * abs(finals[0][0])
+        assert torch.equal(flat, finals[0][1])
+
+
+def test_rgb_error_behaviour():
+    model = _rgb(8, 64, torch.float32)
+    with pytest.raises(RuntimeError):
+        model(torch.rand(1, 3, 64, 64))                  # CPU tensor: no CPU path
+    with pytest.raises(RuntimeError):
+        model(torch.rand(1, 2, 64, 64, device=DEV))      # wrong channel count
+    with pytest.raises(RuntimeError):
+        model.inc(torch.rand(1, 3, 64, 64, device=DEV))  # inner blocks are not callable on their own

@@ -125,3 +125,68 @@ def test_optim_cases(opt):
                                                                weight_decay=wd, decoupled=(opt == 'AdamW'),
                                                                grad_scale=coef)
             np.testing.assert_allclose(ps[i], z[f'{opt}/p{step + 1}/{i}'], rtol=2e-5, atol=2e-6)
+
+
+# ---- DoubleConv family (RGBDepthNet, BinauralAttentionDepthNet) -----------------------------------------
+def _dc_param_keys(z):
+    return [k[len('grad/'):] for k in z.files if k.startswith('grad/')]
+
+
+def test_rgbdepthnet_oracle_matches_reference():
+    """oracle.dcnet_oracle.rgb_forward + depth_loss vs reference RGBDepthNet / DepthLoss / AdamW step."""
+    from oracle import dcnet_oracle
+    z = _load('rgb64_bc8')
+    lr, wd, max_depth, l1w, sw = [float(v) for v in z['hyper']]
+    sd = _sd(z, 'sd0/')
+    image, gt = torch.from_numpy(z['image']), torch.from_numpy(z['gt'])
+    with torch.no_grad():
+        pe, _ = dcnet_oracle.rgb_forward(sd, image, max_depth, training=False)
+    np.testing.assert_allclose(pe.numpy(), z['pred_eval'], rtol=1e-5, atol=1e-5)
+    pkeys = _dc_param_keys(z)
+    for k in pkeys:
+        sd[k] = sd[k].clone().requires_grad_(True)
+    pred, new_stats, feats = dcnet_oracle.rgb_forward(sd, image, max_depth, training=True, return_features=True)
+    np.testing.assert_allclose(pred.detach().numpy(), z['pred_train'], rtol=1e-5, atol=1e-5)
+    for k in ('x1', 'x5', 'd4', 'd1'):
+        np.testing.assert_allclose(feats[k].detach().numpy(), z['feat/' + k], rtol=1e-5, atol=1e-5)
+    pred.retain_grad()
+    loss = dcnet_oracle.depth_loss(pred, gt, l1w, sw)
+    assert abs(loss.item() - float(z['loss'])) <= 1e-6 * abs(float(z['loss']))
+    loss.backward()
+    np.testing.assert_allclose(pred.grad.numpy(), z['pred_grad'], rtol=1e-6, atol=1e-9)
+    for k in pkeys:
+        ref = z['grad/' + k]
+        np.testing.assert_allclose(sd[k].grad.numpy(), ref, rtol=2e-3, atol=1e-6 + 1e-4 * np.abs(ref).max())
+    for k, v in new_stats.items():
+        np.testing.assert_allclose(v.numpy(), z['sd1/' + k], rtol=1e-5, atol=1e-6)
+    for k in pkeys:                                             # AdamW(lr, weight_decay), no clipping
+        p1, _, _ = optim_oracle.adamw_step(sd[k].detach().numpy(), sd[k].grad.numpy(), np.zeros(sd[k].shape),
+                                           np.zeros(sd[k].shape), 1, lr, weight_decay=wd)
+        np.testing.assert_allclose(p1, z['sd1/' + k], rtol=1e-4, atol=2e-6)
+
+
+def test_binaural_oracle_matches_reference():
+    """oracle.dcnet_oracle.binaural_forward (two encoders, cross-attention, fusion, decoder) vs the reference."""
+    from oracle import dcnet_oracle
+    z = _load('binaural64_bc8')
+    lr, wd, max_depth, l1w, sw, lam = [float(v) for v in z['hyper']]
+    sd = _sd(z, 'sd0/')
+    audio, gt = torch.from_numpy(z['audio']), torch.from_numpy(z['gt'])
+    with torch.no_grad():
+        pe, _ = dcnet_oracle.binaural_forward(sd, audio, max_depth, training=False)
+    np.testing.assert_allclose(pe.numpy(), z['pred_eval'], rtol=1e-5, atol=1e-5)
+    pkeys = _dc_param_keys(z)
+    for k in pkeys:
+        sd[k] = sd[k].clone().requires_grad_(True)
+    pred, new_stats = dcnet_oracle.binaural_forward(sd, audio, max_depth, training=True)
+    np.testing.assert_allclose(pred.detach().numpy(), z['pred_train'], rtol=1e-5, atol=1e-5)
+    loss = loss_oracle.masked_loss(pred, gt, 'Combined', l1w, sw, lam, mask_mode='gt0')
+    assert abs(loss.item() - float(z['loss'])) <= 1e-5 * abs(float(z['loss']))
+    loss.backward()
+    for k in pkeys:
+        ref = z['grad/' + k]
+        if k.startswith('fusion_layers') and k.endswith('.0.bias'):
+            continue        # a bias in front of BatchNorm: the true gradient is 0, the reference holds float noise
+        np.testing.assert_allclose(sd[k].grad.numpy(), ref, rtol=5e-3, atol=1e-6 + 2e-4 * np.abs(ref).max())
+    for k, v in new_stats.items():
+        np.testing.assert_allclose(v.numpy(), z['sd1/' + k], rtol=1e-5, atol=1e-6)
