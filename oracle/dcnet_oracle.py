@@ -37,12 +37,44 @@ def _bn(x, sd, key, training, new_stats):
     return F.batch_norm(x, rm, rv, w, b, False, BN_MOMENTUM, BN_EPS)
 
 
+TAPS = None     # tests may set this to a dict to capture the raw conv outputs (with retain_grad) by key
+QUANT = None    # tests may set this to a rounding function (e.g. to bf16 and back) that is applied at the HIP
+#                 engine's storage points -- conv operands, the stored raw conv output, the stored activations --
+#                 with a straight-through gradient: the oracle then models "bf16 storage, exact arithmetic",
+#                 which is what the bf16 engine computes up to accumulation order.
+
+
+def _q(t):
+    return t if QUANT is None else t + (QUANT(t) - t).detach()
+
+
+def _tap(key, h):
+    if TAPS is not None:
+        if h.requires_grad:
+            h.retain_grad()
+        TAPS[key] = h
+    return h
+
+
+def _conv_bn_relu(sd, conv_key, bn_key, x, training, new_stats, bias=None, padding=1):
+    z = _tap(conv_key, F.conv2d(x, _q(sd[conv_key + '.weight']), bias, padding=padding))
+    if QUANT is None or not training:
+        return _q(F.relu(_bn(z, sd, bn_key, training, new_stats)))      # eval: BN is fused into the GEMM epilogue
+    # engine semantics: batch statistics from the f32 accumulators, normalisation of the STORED (rounded) z
+    mu, var = z.mean((0, 2, 3)), z.var((0, 2, 3), unbiased=False)
+    n = z.numel() // z.shape[1]
+    new_stats[bn_key + '.running_mean'] = (1 - BN_MOMENTUM) * sd[bn_key + '.running_mean'] + BN_MOMENTUM * mu.detach()
+    new_stats[bn_key + '.running_var'] = ((1 - BN_MOMENTUM) * sd[bn_key + '.running_var'] +
+                                          BN_MOMENTUM * var.detach() * n / max(n - 1, 1))
+    sc = sd[bn_key + '.weight'] / torch.sqrt(var + BN_EPS)
+    y = (_q(z) - mu.view(1, -1, 1, 1)) * sc.view(1, -1, 1, 1) + sd[bn_key + '.bias'].view(1, -1, 1, 1)
+    return _q(F.relu(y))
+
+
 def double_conv(sd, prefix, x, training, new_stats):
     """(conv3x3 no bias -> BN -> ReLU) x 2; ``prefix`` ends in '.double_conv' (rgb_depth_model.py:28-35)."""
-    h = F.conv2d(x, sd[prefix + '.0.weight'], None, padding=1)
-    h = F.relu(_bn(h, sd, prefix + '.1', training, new_stats))
-    h = F.conv2d(h, sd[prefix + '.3.weight'], None, padding=1)
-    return F.relu(_bn(h, sd, prefix + '.4', training, new_stats))
+    h = _conv_bn_relu(sd, prefix + '.0', prefix + '.1', x, training, new_stats)
+    return _conv_bn_relu(sd, prefix + '.3', prefix + '.4', h, training, new_stats)
 
 
 def down(sd, prefix, x, training, new_stats):
@@ -52,7 +84,7 @@ def down(sd, prefix, x, training, new_stats):
 
 def up(sd, prefix, x1, x2, training, new_stats):
     """bilinear x2 (align_corners=True) -> pad to the skip -> cat([skip, up]) -> DoubleConv (:61-77)."""
-    x1 = F.interpolate(x1, scale_factor=2, mode='bilinear', align_corners=True)
+    x1 = _q(F.interpolate(x1, scale_factor=2, mode='bilinear', align_corners=True))
     dy, dx = x2.shape[2] - x1.shape[2], x2.shape[3] - x1.shape[3]
     x1 = F.pad(x1, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
     return double_conv(sd, prefix + '.conv.double_conv', torch.cat([x2, x1], 1), training, new_stats)
@@ -79,7 +111,7 @@ def rgb_forward(sd, x, max_depth=30.0, training=True, return_features=False):
     """RGBDepthNet.forward (rgb_depth_model.py:148-218) for output_size == input size.
     Returns (depth, new_running_stats[, features])."""
     new_stats = {}
-    feats = encoder(sd, '', x, training, new_stats)
+    feats = encoder(sd, '', _q(x), training, new_stats)
     ds = decoder(sd, feats, training, new_stats)
     depth = F.conv2d(ds[3], sd['outc.weight'], sd['outc.bias'])
     depth = torch.clamp(depth, 0, max_depth)                                  # :209

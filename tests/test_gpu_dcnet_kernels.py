@@ -49,6 +49,8 @@ S1_SHAPES = [
     (3, 128, 0, 128, 2, 2, 3),      # tiny grid: every tap partly padded; split-K
     (8, 64, 0, 128, 32, 32, 3),     # fused LDS epilogue
     (4, 128, 128, 64, 64, 64, 3),   # 256-row tiles
+    (2, 64, 64, 64, 64, 64, 3),     # RGBDepthNet up4.conv1 at 64x64 (split-K, two segments in the dgrad)
+    (2, 128, 0, 64, 32, 32, 3),     # up3.conv2
     (2, 8, 0, 64, 16, 16, 3),       # thin input: narrow loader, K = 72 padded to the K-step
     (2, 16, 0, 64, 7, 9, 3),        # narrow, odd sizes
     (2, 6, 0, 10, 5, 5, 3),         # generic direct path
@@ -217,7 +219,7 @@ def test_conv_wgrad_s1_thin_input(dtype):
 
 
 # ---------------------------------------------------------------------------------------------------------
-EW_SHAPES = [(2, 16, 8, 12), (2, 64, 16, 16), (1, 5, 7, 9), (3, 8, 2, 2)]      # (B, C, H, W)
+EW_SHAPES = [(2, 16, 8, 12), (2, 64, 16, 16), (1, 5, 7, 9), (3, 8, 2, 2), (2, 64, 64, 64)]      # (B, C, H, W)
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
@@ -246,7 +248,7 @@ def test_maxpool2(dtype, shape):
 
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('shape', [(2, 16, 4, 6, 0, 0), (2, 64, 8, 8, 0, 0), (1, 5, 3, 4, 1, 1), (2, 8, 1, 1, 0, 1),
-                                   (2, 8, 16, 16, 0, 0)])
+                                   (2, 8, 16, 16, 0, 0), (2, 64, 32, 32, 0, 0), (2, 128, 16, 16, 0, 0)])
 def test_upsample2x(dtype, shape):
     """Up: bilinear x2 align_corners=True, then F.pad to the skip size (rgb_depth_model.py:61-75)."""
     B, C, Hi, Wi, dH, dW = shape
@@ -267,7 +269,8 @@ def test_upsample2x(dtype, shape):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('shape', [(2, 64, 16, 16), (4, 128, 32, 32), (2, 5, 7, 9), (1, 8, 3, 3), (2, 512, 4, 4)])
+@pytest.mark.parametrize('shape', [(2, 64, 16, 16), (4, 128, 32, 32), (2, 5, 7, 9), (1, 8, 3, 3), (2, 512, 4, 4),
+                                   (2, 64, 32, 32), (2, 64, 64, 64)])
 def test_relu_bwd_stats(dtype, shape):
     B, C, H, W = shape
     torch.manual_seed(8)
