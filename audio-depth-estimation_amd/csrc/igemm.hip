@@ -505,7 +505,8 @@ bool make_plan(const AdnIgemmDesc* d, Plan* pl) {
   pl->phases = d->geom == ADN_GEMM_T2 ? 4 : 1;
   pl->mout = msmall * pl->phases;
   const int taps = d->geom == ADN_GEMM_S2 ? 16 : (d->geom == ADN_GEMM_T2 ? 4 : d->ks * d->ks);
-  pl->wstride = (int)(adn_cdiv((int64_t)taps * Cin, bk) * bk);
+  // S1 operands (adn_pack_rows / adn_pack_transpose_taps) pad their rows to the K-step; the k4 packs do not
+  pl->wstride = d->geom == ADN_GEMM_S1 ? (int)(adn_cdiv((int64_t)taps * Cin, bk) * bk) : taps * Cin;
   const int epc = 16 / esz;
   // wide: every K-step lies inside one tap of one source; narrow: single source, several taps per K-step
   pl->wide = (d->C0 % bk == 0) && (d->C1 % bk == 0);

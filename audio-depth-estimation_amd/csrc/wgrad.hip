@@ -32,7 +32,7 @@ __device__ u32x4_t adn_wg_zero_page[8];
 
 __device__ __forceinline__ int swz_f(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
-template <typename T, bool FAST>
+template <typename T, bool FAST, bool MIXED>
 __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins exist only in the device pass
   constexpr int EPC = 16 / (int)sizeof(T);
@@ -124,18 +124,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
   constexpr int ESZ = (int)sizeof(T);
   unsigned pvoff[PASSES], gvoff[PASSES];
   bool m_y0[PASSES], m_y1[PASSES], m_x0[PASSES], m_x1[PASSES], m_c[PASSES];
-  __amdgpu_buffer_rsrc_t rsp, rsg;
+  __amdgpu_buffer_rsrc_t rsp, rsg, rsg1;
+  bool lsec[PASSES];
+  constexpr bool mixed = MIXED;
   int Rs_u = 0, Cs_u = 0, lgWs = 0;
   if constexpr (FAST) {
     lgWs = 31 - __builtin_clz((unsigned)Ws);
     const bool psecond = tile_r * 128 >= p.R0;
     Rs_u = psecond ? p.R1 : p.R0;
     const char* pb = reinterpret_cast<const char*>(psecond ? p.plain1 : p.plain0);
-    const bool gsecond = (C >= 128) && ((tile_c * 128) % C) >= p.C0;
+    // a 128-column tile normally lies inside one gathered source; when it does not (C0 = C1 = 64, or several
+    // taps of a narrow two-source concat per tile) the source is a per-lane constant and the two descriptors
+    // are selected by an exec-masked branch
+    const bool gsecond = !mixed && (C >= 128) && ((tile_c * 128) % C) >= p.C0;
     Cs_u = gsecond ? p.C1 : p.C0;
     const char* gb = reinterpret_cast<const char*>(gsecond ? p.gath1 : p.gath0) - (int64_t)kpad * (Wl + 1) * Cs_u * ESZ;
     rsp = __builtin_amdgcn_make_buffer_rsrc((void*)pb, 0, 0x7ffffff0, 0x00020000);
     rsg = __builtin_amdgcn_make_buffer_rsrc((void*)gb, 0, 0x7ffffff0, 0x00020000);
+    rsg1 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(reinterpret_cast<const char*>(p.C1 ? p.gath1 : p.gath0) - (int64_t)kpad * (Wl + 1) * p.C1 * ESZ), 0,
+        0x7ffffff0, 0x00020000);
     const bool rows_in_line = Ws >= BKP;          // a step stays inside one image row
     const int q = rows_in_line ? 1 : BKP / Ws;    // image rows per step otherwise
 #pragma unroll
@@ -149,11 +157,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
       pvoff[k] = r_ok[v] ? (unsigned)((r * Rs_u + roff) * ESZ) : OOB;
       const int gcol = tile_c * 128 + lc * EPC;
       const int tap = gcol / C;
-      const int cch = gcol - tap * C - (gsecond ? p.C0 : 0);
+      int cch = gcol - tap * C - (gsecond ? p.C0 : 0);
+      int Cs_l = Cs_u;
+      lsec[k] = false;
+      if (mixed && cch >= p.C0) {
+        lsec[k] = true;
+        cch -= p.C0;
+        Cs_l = p.C1;
+      }
       const int jx = r & (Ws - 1);
       // linear index of the gathered pixel at tap (kpad,kpad): s2: 4m - 2j, s1: m  (scalar part + lane part)
       const int L = s1 ? r : (rows_in_line ? 2 * r : 4 * r - 2 * jx);
-      gvoff[k] = (unsigned)(((L + ky[v] * Wl + kx[v]) * Cs_u + cch) * ESZ);
+      gvoff[k] = (unsigned)(((L + ky[v] * Wl + kx[v]) * Cs_l + cch) * ESZ);
       const int a = r >> lgWs;                    // image row inside the step (0 when rows_in_line)
       const int klast = kside - 1;
       m_y0[k] = has_pad && (ky[v] == 0) && (rows_in_line || a == 0);
@@ -177,13 +192,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
       const bool top = si == 0, bot = si == Hs - q;
       const bool left = rows_in_line && sj == 0, right = rows_in_line && sj == Ws - BKP;
       const int psoff = m0 * Rs_u * ESZ;
-      const int gsoff = (s1 ? m0 : 4 * m0 - 2 * sj) * Cs_u * ESZ;
+      const int gpix = s1 ? m0 : 4 * m0 - 2 * sj;
+      const int gsoff = gpix * Cs_u * ESZ;
+      const int gsoff1 = gpix * p.C1 * ESZ;
 #pragma unroll
       for (int k = 0; k < PASSES; ++k) {
         const bool inval = m_c[k] || (top && m_y0[k]) || (bot && m_y1[k]) || (left && m_x0[k]) || (right && m_x1[k]);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsp, (lptr_t)(pdst + k * (RPP * ROWB)), 16, pvoff[k], psoff, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsg, (lptr_t)(gdst + k * (RPP * ROWB)), 16,
-                                                 inval ? OOB : gvoff[k], gsoff, 0, 0);
+        const unsigned gv = inval ? OOB : gvoff[k];
+        if constexpr (MIXED) {
+          // LDS-DMA lands at M0 base + lane * 16 for ACTIVE lanes only, so the two masked halves compose
+          if (lsec[k]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsg1, (lptr_t)(gdst + k * (RPP * ROWB)), 16, gv, gsoff1, 0, 0);
+          else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsg, (lptr_t)(gdst + k * (RPP * ROWB)), 16, gv, gsoff, 0, 0);
+        } else {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsg, (lptr_t)(gdst + k * (RPP * ROWB)), 16, gv, gsoff, 0, 0);
+        }
       }
     } else {
 #pragma unroll
@@ -388,6 +411,7 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* slab, float*
 struct WPlan {
   bool mfma;
   bool fast;
+  bool mixed;    // fast path whose 128-column tiles straddle the two gathered sources
   int nsplit, steps, tiles_r, tiles_c, pix_per_split;
   int64_t out_elems, slab_bytes;
 };
@@ -404,14 +428,15 @@ void make_wplan(const AdnWgradDesc* d, WPlan* pl) {
                        (C >= 128 ? (C % 128 == 0) : (128 % C == 0));
   pl->mfma = aligned;
   pl->fast = false;
+  pl->mixed = false;
   if (aligned) {
     const int bkp = d->dtype == ADN_BF16 ? 64 : 32;
     const int64_t esz = d->dtype == ADN_BF16 ? 2 : 4;
     auto pow2 = [](int x) { return x > 0 && (x & (x - 1)) == 0; };
     pl->fast = pow2(d->Hs) && pow2(d->Ws) && d->Hs * d->Ws >= bkp && (d->R1 == 0 || d->R0 % 128 == 0) &&
-               (d->C1 == 0 || (d->C0 % 128 == 0 && C % 128 == 0)) &&
                msmall * (d->geom == ADN_GEMM_S1 ? 1 : 4) * (d->C0 > d->C1 ? d->C0 : d->C1) * esz < (1ll << 31) &&
                msmall * (d->R0 > d->R1 ? d->R0 : d->R1) * esz < (1ll << 31);     // 32-bit scalar byte offsets
+    pl->mixed = pl->fast && d->C1 > 0 && (C < 128 || (d->C0 % 128) != 0);
     pl->steps = (int)adn_cdiv(msmall, bkp);
     pl->tiles_r = (int)adn_cdiv(R, 128);
     pl->tiles_c = (int)adn_cdiv((int64_t)ntap * C, 128);
@@ -468,16 +493,18 @@ int wrun(const AdnWgradDesc* d, const WPlan& pl, hipStream_t st) {
     constexpr int lds = stage > epil ? stage : epil;
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_kernel<T, true>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_kernel<T, false>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_kernel<T, true, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_kernel<T, true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_kernel<T, false, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       attr_set = true;
     }
-    if (pl.fast)
-      hipLaunchKernelGGL((wgrad_mfma_kernel<T, true>), dim3(pl.tiles_r * pl.tiles_c * pl.nsplit), dim3(256), lds, st, p);
-    else
-      hipLaunchKernelGGL((wgrad_mfma_kernel<T, false>), dim3(pl.tiles_r * pl.tiles_c * pl.nsplit), dim3(256), lds, st, p);
+    const dim3 grid(pl.tiles_r * pl.tiles_c * pl.nsplit);
+    if (pl.fast && pl.mixed) hipLaunchKernelGGL((wgrad_mfma_kernel<T, true, true>), grid, dim3(256), lds, st, p);
+    else if (pl.fast) hipLaunchKernelGGL((wgrad_mfma_kernel<T, true, false>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((wgrad_mfma_kernel<T, false, false>), grid, dim3(256), lds, st, p);
   } else {
     hipLaunchKernelGGL((wgrad_direct_kernel<T>), dim3((unsigned)adn_cdiv(pl.out_elems, 256), pl.nsplit), dim3(256),
                        0, st, p, pl.pix_per_split);

@@ -29,6 +29,15 @@ WGRAD = [('L1_wgrad', 64, 128, 0, 64), ('L2_wgrad', 32, 256, 0, 128), ('L3_wgrad
          ('D1_wgrad', 64, 128, 128, 64), ('D2_wgrad', 32, 256, 256, 128), ('D3_wgrad', 16, 512, 512, 256)]
 
 
+# stride-1 3x3 layers of the DoubleConv nets (RGBDepthNet, 256x256, B=32): name, H, C0, C1, N
+S1_IGEMM = [('s1_inc2_fwd', 256, 64, 0, 64), ('s1_up4c1_fwd', 256, 64, 64, 64), ('s1_up4c1_dgrad', 256, 64, 0, 128),
+            ('s1_d1c2_fwd', 128, 128, 0, 128), ('s1_up3c1_fwd', 128, 128, 128, 128), ('s1_d2c2_fwd', 64, 256, 0, 256),
+            ('s1_d3c2_fwd', 32, 512, 0, 512)]
+# name, H, R, C0, C1
+S1_WGRAD = [('s1_inc2_wgrad', 256, 64, 64, 0), ('s1_up4c1_wgrad', 256, 64, 64, 64), ('s1_d1c2_wgrad', 128, 128, 128, 0),
+            ('s1_up3c1_wgrad', 128, 128, 128, 128), ('s1_d2c2_wgrad', 64, 256, 256, 0), ('s1_d3c2_wgrad', 32, 512, 512, 0)]
+
+
 def timeit(fn, iters):
     for _ in range(3):
         fn()
@@ -46,8 +55,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--only', default=None)
+    ap.add_argument('--s1', action='store_true', help='stride-1 3x3 shapes of the DoubleConv nets instead')
     args = ap.parse_args()
     torch.manual_seed(0)
+    if args.s1:
+        return s1_main(args)
     for name, geom, Hs, C0, C1, N in IGEMM:
         if args.only and args.only not in name:
             continue
@@ -77,6 +89,36 @@ def main():
         t = timeit(fn, args.iters)
         fl = 2.0 * B * Hs * Hs * (R0 + R1) * 16 * C
         print(f'{name:10s} M={B*Hs*Hs:7d} R={R0+R1:4d} C={C:4d}        {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF/s (incl. slab sum)', flush=True)
+
+
+def s1_main(args):
+    for name, H, C0, C1, N in S1_IGEMM:
+        if args.only and args.only not in name:
+            continue
+        in0 = torch.randn(B, H, H, C0, device=DEV).to(T)
+        in1 = torch.randn(B, H, H, C1, device=DEV).to(T) if C1 else None
+        w = (torch.randn(N, K.s1_row_stride(T, 9, C0 + C1), device=DEV) * 0.05).to(T)
+        out = torch.empty(B, H, H, N, device=DEV, dtype=T)
+        P, wsb = K.igemm_query(T, K.GEMM_S1, B, H, H, C0, C1, N, [N], ks=3)
+        ws = torch.empty(max(wsb, 16) // 4, device=DEV)
+        part = torch.empty(P * 2 * N, device=DEV)
+        fn = lambda: K.igemm(T, K.GEMM_S1, B, H, H, in0, in1, w, N, 1, [K.Seg(N, out0=out, partials=part)], ws, ks=3)
+        t = timeit(fn, args.iters)
+        fl = 2.0 * B * H * H * N * 9 * (C0 + C1)
+        print(f'{name:15s} M={B*H*H:8d} N={N:4d} K={9*(C0+C1):5d}  {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF/s', flush=True)
+    for name, H, R, C0, C1 in S1_WGRAD:
+        if args.only and args.only not in name:
+            continue
+        p0 = torch.randn(B, H, H, R, device=DEV).to(T)
+        g0 = torch.randn(B, H, H, C0, device=DEV).to(T)
+        g1 = torch.randn(B, H, H, C1, device=DEV).to(T) if C1 else None
+        dw = torch.empty(R * 9 * (C0 + C1), device=DEV)
+        ws = torch.empty(max(K.wgrad_workspace_bytes(T, B, H, H, R, 0, C0, C1, ks=3), 16) // 4, device=DEV)
+        fn = lambda: K.wgrad(T, B, H, H, p0, None, g0, g1, dw, ws, ks=3)
+        t = timeit(fn, args.iters)
+        fl = 2.0 * B * H * H * R * 9 * (C0 + C1)
+        print(f'{name:15s} M={B*H*H:8d} R={R:4d} C={C0+C1:4d}        {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF/s (incl. slab sum)',
+              flush=True)
 
 
 if __name__ == '__main__':
