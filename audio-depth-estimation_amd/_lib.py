@@ -49,6 +49,20 @@ class AdnWgradDesc(C.Structure):
     ]
 
 
+class AdnAttnDesc(C.Structure):
+    _fields_ = [
+        ('dtype', c_int32), ('B2', c_int32), ('N', c_int32), ('dqk', c_int32), ('dv', c_int32), ('kv_shift', c_int32),
+        ('q', c_void_p), ('k', c_void_p), ('v', c_void_p),
+        ('ld_q', c_int32), ('ld_k', c_int32), ('ld_v', c_int32),
+        ('o', c_void_p), ('ld_o', c_int32),
+        ('lse', c_void_p), ('scale', c_float),
+        ('dout', c_void_p), ('ld_do', c_int32),
+        ('dq', c_void_p), ('dk', c_void_p), ('dvp', c_void_p),
+        ('ld_dq', c_int32), ('ld_dk', c_int32), ('ld_dv', c_int32),
+        ('workspace', c_void_p), ('workspace_bytes', c_int64),
+    ]
+
+
 # name -> (restype, argtypes).  Must list every symbol include/adn.h declares
 # (tests/test_abi.py cross-checks this table against the header and the built library).
 _PROTOS = {
@@ -78,6 +92,14 @@ _PROTOS = {
     'adn_l1tv_finish': (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     'adn_nchw_to_nhwc': (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                    c_void_p]),
+    'adn_nchw_slice_to_nhwc': (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    'adn_attn_fwd': (C.c_int, [C.POINTER(AdnAttnDesc), c_void_p]),
+    'adn_attn_bwd_workspace_bytes': (c_int64, [C.POINTER(AdnAttnDesc)]),
+    'adn_attn_bwd': (C.c_int, [C.POINTER(AdnAttnDesc), c_void_p]),
+    'adn_channel_sum_workspace_bytes': (c_int64, [c_int64, c_int32]),
+    'adn_channel_sum': (C.c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
+    'adn_gate_bwd': (C.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                               c_void_p]),
     'adn_nhwc_to_nchw': (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     'adn_bn_fwd_finalize': (C.c_int, [c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p, c_float, c_float,
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -54,14 +54,14 @@ __global__ __launch_bounds__(256) void pack_t2_kernel(const float* master, int X
 // one thread per pixel: C coalesced plane reads, one contiguous Cpad-element write
 template <typename T>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* src, T* dst, int B, int C, int Cpad,
-                                                           int64_t HW) {
+                                                           int64_t HW, int64_t Ctot) {
   const int64_t npix = (int64_t)B * HW;
   for (int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x; pix < npix; pix += (int64_t)gridDim.x * 256) {
     const int64_t b = pix / HW, hw = pix - b * HW;
     for (int c0 = 0; c0 < Cpad; c0 += 8) {
       float f[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) f[k] = (c0 + k < C) ? src[(b * C + c0 + k) * HW + hw] : 0.0f;
+      for (int k = 0; k < 8; ++k) f[k] = (c0 + k < C) ? src[(b * Ctot + c0 + k) * HW + hw] : 0.0f;
       if (c0 + 8 <= Cpad && (Cpad & 7) == 0) {
         store8<T>(dst, pix * Cpad + c0, f);
       } else {
@@ -323,20 +323,27 @@ extern "C" int adn_pack_weights(const float* master, int32_t X, int32_t Y, int32
   return ADN_OK;
 }
 
-extern "C" int adn_nchw_to_nhwc(const float* src, void* dst, int32_t B, int32_t C, int32_t c_pad, int32_t H,
-                                int32_t W, int32_t dtype, void* stream) {
-  ADN_CHECK_ARG(src && dst && B > 0 && C > 0 && c_pad >= C && H > 0 && W > 0, "adn_nchw_to_nhwc: bad arguments");
-  ADN_CHECK_ARG(dtype == ADN_F32 || dtype == ADN_BF16, "adn_nchw_to_nhwc: bad dtype %d", dtype);
+extern "C" int adn_nchw_slice_to_nhwc(const float* src, void* dst, int32_t B, int32_t C_total, int32_t c_lo, int32_t C,
+                                      int32_t c_pad, int32_t H, int32_t W, int32_t dtype, void* stream) {
+  ADN_CHECK_ARG(src && dst && B > 0 && C > 0 && c_pad >= C && H > 0 && W > 0 && c_lo >= 0 && c_lo + C <= C_total,
+                "adn_nchw_slice_to_nhwc: bad arguments");
+  ADN_CHECK_ARG(dtype == ADN_F32 || dtype == ADN_BF16, "adn_nchw_slice_to_nhwc: bad dtype %d", dtype);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int64_t n = (int64_t)B * H * W;
+  const float* s0 = src + (int64_t)c_lo * H * W;
   if (dtype == ADN_BF16)
-    hipLaunchKernelGGL((nchw_to_nhwc_kernel<uint16_t>), dim3(blocks_for(n)), dim3(256), 0, st, src,
-                       reinterpret_cast<uint16_t*>(dst), B, C, c_pad, (int64_t)H * W);
+    hipLaunchKernelGGL((nchw_to_nhwc_kernel<uint16_t>), dim3(blocks_for(n)), dim3(256), 0, st, s0,
+                       reinterpret_cast<uint16_t*>(dst), B, C, c_pad, (int64_t)H * W, (int64_t)C_total);
   else
-    hipLaunchKernelGGL((nchw_to_nhwc_kernel<float>), dim3(blocks_for(n)), dim3(256), 0, st, src,
-                       reinterpret_cast<float*>(dst), B, C, c_pad, (int64_t)H * W);
+    hipLaunchKernelGGL((nchw_to_nhwc_kernel<float>), dim3(blocks_for(n)), dim3(256), 0, st, s0,
+                       reinterpret_cast<float*>(dst), B, C, c_pad, (int64_t)H * W, (int64_t)C_total);
   ADN_CHECK_LAUNCH();
   return ADN_OK;
+}
+
+extern "C" int adn_nchw_to_nhwc(const float* src, void* dst, int32_t B, int32_t C, int32_t c_pad, int32_t H,
+                                int32_t W, int32_t dtype, void* stream) {
+  return adn_nchw_slice_to_nhwc(src, dst, B, C, 0, C, c_pad, H, W, dtype, stream);
 }
 
 extern "C" int adn_nhwc_to_nchw(const void* src, float* dst, int32_t B, int32_t C, int32_t H, int32_t W,

@@ -39,6 +39,9 @@ __device__ __forceinline__ void epi_scalar(int epi, const AdnEpiSeg& sg, int64_t
     }
   } else if (epi == ADN_EPI_ADD) {
     float g = v;
+    if (sg.bias) g += sg.bias[nl];
+    if (sg.scale) g *= sg.final_act ? sg.scale[0] : sg.scale[nl];
+    if (sg.ref) g += ElemTraits<T>::load(reinterpret_cast<const T*>(sg.ref) + idx);
     if (sg.accumulate) g += ElemTraits<T>::load(reinterpret_cast<const T*>(sg.out0) + idx);
     ElemTraits<T>::store(reinterpret_cast<T*>(sg.out0) + idx, g);
   } else {  // ADN_EPI_FINAL
@@ -100,6 +103,12 @@ __device__ __forceinline__ void epi_cols_init(int epi, const AdnEpiSeg& sg, int 
   } else if ((epi == ADN_EPI_FINAL || epi == ADN_EPI_Z_STATS) && sg.bias) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) c.b[e] = sg.bias[nl + e];
+  } else if (epi == ADN_EPI_ADD) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (sg.scale) c.a[e] = sg.final_act ? sg.scale[0] : sg.scale[nl + e];
+      if (sg.bias) c.b[e] = sg.bias[nl + e];
+    }
   }
 }
 
@@ -157,7 +166,13 @@ __device__ __forceinline__ void epi_vec8(int epi, const AdnEpiSeg& sg, const Epi
   } else if (epi == ADN_EPI_ADD) {
     float g[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) g[e] = v[e];
+    for (int e = 0; e < 8; ++e) g[e] = (v[e] + c.b[e]) * c.a[e];       // a = 1, b = 0 when not given
+    if (sg.ref) {
+      float r[8];
+      load8<T>(sg.ref, idx, r);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] += r[e];
+    }
     if (sg.accumulate) {
       float old[8];
       load8<T>(sg.out0, idx, old);

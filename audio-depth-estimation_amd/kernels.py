@@ -10,6 +10,7 @@ import ctypes as C
 import torch
 
 from . import _lib
+from ._lib import AdnAttnDesc  # noqa: E402
 from ._lib import (ADN_BF16, ADN_F32, EPI_ACT, EPI_ADD, EPI_BWD, EPI_FINAL, EPI_RAW, EPI_Z_STATS, GEMM_S1, GEMM_S2, GEMM_T2,
                    AdnEpiSeg, AdnIgemmDesc, AdnWgradDesc, ptr)
 
@@ -404,3 +405,65 @@ def l1tv_finish(pred, gt, stats, replicas, lambda_l1, lambda_smooth, loss_out, g
     _dev(pred, gt, stats, loss_out, grad)
     _lib.call('adn_l1tv_finish', ptr(pred), ptr(gt), B, H, W, ptr(stats), int(replicas), float(lambda_l1),
               float(lambda_smooth), ptr(loss_out), ptr(grad), _stream())
+
+
+# ---- binaural cross-attention (csrc/attn.hip, attn_mfma.hip) -----------------------------------------------
+def nchw_slice_to_nhwc(src, c_lo, Cc, dst):
+    """Channels [c_lo, c_lo + Cc) of src f32 [B,Ct,H,W] -> dst [B,H,W,Cpad] (extra channels zero)."""
+    B, Ct, H, W = src.shape
+    _dev(src, dst)
+    _lib.call('adn_nchw_slice_to_nhwc', ptr(src), ptr(dst), B, Ct, c_lo, Cc, dst.shape[-1], H, W, dtype_code(dst.dtype),
+              _stream())
+
+
+def _esz(t):
+    return t.element_size()
+
+
+def _attn_desc(q, k, v, o, lse, dqk, dv, kv_shift, scale, dout=None, dq=None, dk=None, dvg=None, workspace=None):
+    """q/k/v/o (and gradients) are [B2, N, *] views whose last-dim stride is 1 and row stride = stride(1)."""
+    d = AdnAttnDesc()
+    B2, N = q.shape[0], q.shape[1]
+    d.dtype, d.B2, d.N, d.dqk, d.dv, d.kv_shift = dtype_code(q.dtype), B2, N, dqk, dv, kv_shift
+    for t in (q, k, v, o, dout, dq, dk, dvg):
+        if t is not None:
+            assert t.stride(-1) == 1 and t.stride(0) == N * t.stride(1), 'attention operands must be [B2,N,ld] row views'
+    _dev(q, k, v, o, lse, dout, dq, dk, dvg, workspace)
+    d.q, d.k, d.v, d.o, d.lse = ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse)
+    d.ld_q, d.ld_k, d.ld_v, d.ld_o = q.stride(1), k.stride(1), v.stride(1), o.stride(1)
+    d.scale = float(scale)
+    if dout is not None:
+        d.dout, d.dq, d.dk, d.dvp = ptr(dout), ptr(dq), ptr(dk), ptr(dvg)
+        d.ld_do, d.ld_dq, d.ld_dk, d.ld_dv = dout.stride(1), dq.stride(1), dk.stride(1), dvg.stride(1)
+        d.workspace = ptr(workspace)
+        d.workspace_bytes = workspace.numel() * workspace.element_size()
+    return d
+
+
+def attn_fwd(q, k, v, o, lse, dqk, dv, kv_shift, scale):
+    d = _attn_desc(q, k, v, o, lse, dqk, dv, kv_shift, scale)
+    _lib.call('adn_attn_fwd', C.byref(d), _stream())
+    _lib.annotate(label='attn_fwd', flops=4.0 * d.B2 * d.N * d.N * (dqk + dv))
+
+
+def attn_bwd(q, k, v, o, lse, dqk, dv, kv_shift, scale, dout, dq, dk, dvg, workspace):
+    d = _attn_desc(q, k, v, o, lse, dqk, dv, kv_shift, scale, dout, dq, dk, dvg, workspace)
+    _lib.call('adn_attn_bwd', C.byref(d), _stream())
+    _lib.annotate(label='attn_bwd', flops=2.0 * d.B2 * d.N * d.N * (3 * dqk + 2 * dv))
+
+
+def channel_sum_workspace_bytes(rows, Cc):
+    return _lib.load().adn_channel_sum_workspace_bytes(rows, Cc)
+
+
+def channel_sum(x, rows, Cc, ld, out, workspace):
+    _dev(x, out, workspace)
+    _lib.call('adn_channel_sum', ptr(x), rows, Cc, ld, dtype_code(x.dtype), ptr(out), ptr(workspace),
+              workspace.numel() * workspace.element_size(), _stream())
+
+
+def gate_bwd(t, att, gamma, gsum, bias, Cc, dgamma, dbias, dw, workspace):
+    _dev(t, att, gamma, gsum, bias, dgamma, dbias, dw, workspace)
+    _lib.call('adn_gate_bwd', ptr(t), ptr(att), t.numel(), dtype_code(t.dtype), ptr(gamma), ptr(gsum), ptr(bias), Cc,
+              ptr(dgamma), ptr(dbias), ptr(dw), dw.numel() if dw is not None else 0, ptr(workspace),
+              workspace.numel() * workspace.element_size(), _stream())

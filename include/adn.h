@@ -55,7 +55,9 @@ enum {
   ADN_EPI_BWD,       /* g = v * (ref>0 ? 1 : slope) (+ out0 if accumulate); out0 = g;
                         optional partial sums of g and g*xhat, xhat=(z-mean)*istd                */
   ADN_EPI_FINAL,     /* out0(f32) = final_act(v + bias[n]); final_act: 0 relu, 1 sigmoid         */
-  ADN_EPI_ADD        /* out0 (dtype) = v (+ out0 if accumulate): plain input-gradient accumulation */
+  ADN_EPI_ADD        /* out0 (dtype) = (v + bias[n]) * scale[n] (+ ref) (+ out0 if accumulate); bias/scale/ref
+                        optional; final_act != 0: scale is ONE device scalar (residual gate gamma).
+                        Plain input-gradient accumulation, linear 1x1 projections, x + gamma * proj(att)   */
 };
 
 /* One channel segment of the output (virtual concat: the output channels [0,N) may be split
@@ -183,12 +185,53 @@ int adn_l1tv_finish(const float* pred, const float* gt, int32_t B, int32_t H, in
                     const double* stats, int32_t replicas, float lambda_l1, float lambda_smooth,
                     float* loss_out, float* grad, void* stream);
 
+/* ---- Binaural cross-attention (BinauralCrossAttention.forward, binaural_attention_model.py:106-153) ----
+ * Streaming-softmax attention over the N = H*W tokens of NHWC tensors; the N x N scores are never stored.
+ * Rows are token-major and channel-contiguous with arbitrary row strides (slices of a fused q|k|v buffer).
+ * Entry b of the B2 stacked batch entries attends from its queries to the keys/values of entry
+ * (b + kv_shift) % B2: [left; right] stacked along the batch gives both directions in one launch.
+ *   forward : o = softmax_keys(scale * q k^T) v,  lse = logsumexp_keys(scale * q k^T)       (:120-127)
+ *   backward: dq, dk, dv from dout (recomputing the probabilities from lse); workspace holds
+ *             D = rowsum(dout * o), f32 [B2][N] (adn_attn_bwd_workspace_bytes). */
+typedef struct {
+  int32_t dtype;
+  int32_t B2, N, dqk, dv, kv_shift;
+  const void* q; const void* k; const void* v;       /* [B2][N][ld_*] */
+  int32_t ld_q, ld_k, ld_v;
+  void* o; int32_t ld_o;                             /* [B2][N][ld_o], written by fwd, read by bwd */
+  float* lse;                                        /* [B2][N] f32 */
+  float scale;                                       /* 1 / sqrt(C) (:121) */
+  /* backward only */
+  const void* dout; int32_t ld_do;
+  void* dq; void* dk; void* dvp;
+  int32_t ld_dq, ld_dk, ld_dv;
+  void* workspace; int64_t workspace_bytes;
+} AdnAttnDesc;
+int adn_attn_fwd(const AdnAttnDesc* d, void* stream);
+int64_t adn_attn_bwd_workspace_bytes(const AdnAttnDesc* d);
+int adn_attn_bwd(const AdnAttnDesc* d, void* stream);
+/* out[c] = sum over rows of x[row][c], x [rows][ld] (bias gradients of the 1x1 projections). */
+int64_t adn_channel_sum_workspace_bytes(int64_t rows, int32_t C);
+int adn_channel_sum(const void* x, int64_t rows, int32_t C, int32_t ld, int32_t dtype, float* out,
+                    void* workspace, int64_t workspace_bytes, void* stream);
+/* Backward of the gated residual x + gamma * out_proj(att) (:130-133).  t (dtype, n elements) holds the
+ * input gradient of out_proj for the UNSCALED upstream gradient G; att the attention output; gsum[c] = sum G.
+ * dgamma = sum(t * att) + sum_c bias[c] * gsum[c];  t <- gamma * t;  dbias = gamma * gsum;  dw *= gamma
+ * (dw = wgrad(G, att) computed by the caller, nw elements).  workspace: 8 KiB. */
+int adn_gate_bwd(void* t, const void* att, int64_t n, int32_t dtype, const float* gamma,
+                 const float* gsum, const float* bias, int32_t C, float* dgamma, float* dbias,
+                 float* dw, int64_t nw, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* NCHW f32 <-> NHWC dtype layout conversion of the network input/output
  * (model(audio) boundary, train.py:642).  dst has c_pad >= C channels, the extra ones zero. */
 int adn_nchw_to_nhwc(const float* src, void* dst, int32_t B, int32_t C, int32_t c_pad, int32_t H,
                      int32_t W, int32_t dtype, void* stream);
 int adn_nhwc_to_nchw(const void* src, float* dst, int32_t B, int32_t C, int32_t H, int32_t W,
                      int32_t dtype, void* stream);
+/* Same for the channel range [c_lo, c_lo + C) of a [B][C_total][H][W] tensor (x[:, 0:1] / x[:, 1:2] split of the
+ * binaural input, binaural_attention_model.py:292-293). */
+int adn_nchw_slice_to_nhwc(const float* src, void* dst, int32_t B, int32_t C_total, int32_t c_lo,
+                           int32_t C, int32_t c_pad, int32_t H, int32_t W, int32_t dtype, void* stream);
 
 /* BatchNorm2d (nn.BatchNorm2d via get_norm_layer('batch'), unetbaseline_model.py:68-69,190-192).
  * Train-mode forward finalize: partial sums [P][2][C] -> mean, istd, scale=gamma*istd,

@@ -350,3 +350,88 @@ def test_l1tv_loss(shape, replicas):
     k.l1tv_finish(pd, gd, stats, replicas, 1.0, 0.1, lo, grad)
     assert abs(float(lo) - float(loss)) <= 1e-6 * abs(float(loss))
     assert rel_err(grad * replicas, pred.grad) <= 1e-5
+
+
+# ---- binaural cross-attention ----------------------------------------------------------------------------
+def _attn_ref(q, k, v, B, scale):
+    """[2B,N,d] stacked [left; right]: entry b attends to entry (b + B) % 2B (binaural_attention_model.py:114-127)."""
+    kk, vv = torch.roll(k, -B, 0), torch.roll(v, -B, 0)
+    s = torch.einsum('bid,bjd->bij', q, kk) * scale
+    p = torch.softmax(s, -1)
+    return torch.einsum('bij,bjc->bic', p, vv), torch.logsumexp(s, -1)
+
+
+# (B, N, dqk, dv)
+ATTN_SHAPES = [(1, 16, 2, 16), (2, 100, 4, 32), (2, 256, 8, 64), (1, 300, 16, 128), (1, 128, 64, 512)]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', ATTN_SHAPES)
+def test_attention_fwd_bwd(dtype, shape):
+    """Streaming-softmax attention vs the explicit softmax(QK^T)V of the reference, forward and backward;
+    q | k | v live in ONE fused projection buffer (row stride = dqk + dqk + dv + padding)."""
+    B, N, dqk, dv = shape
+    B2 = 2 * B
+    torch.manual_seed(11)
+    ld = dqk * 2 + dv + 8
+    qkv = rounded(torch.randn(B2, N, ld), dtype)
+    scale = 1.0 / (dv ** 0.5)
+    q = (qkv[:, :, :dqk] * 2).clone().requires_grad_(True)
+    k = (qkv[:, :, dqk:2 * dqk] * 2).clone().requires_grad_(True)
+    v = qkv[:, :, 2 * dqk:2 * dqk + dv].clone().requires_grad_(True)
+    qkv = torch.cat([q.detach(), k.detach(), v.detach(), qkv[:, :, 2 * dqk + dv:]], -1)
+    o_ref, lse_ref = _attn_ref(q, k, v, B, scale)
+    do = rounded(torch.randn_like(o_ref), dtype)
+    o_ref.backward(do)
+    kk = K()
+    dev_qkv = qkv.to(dtype).to(DEV)
+    qd, kd, vd = dev_qkv[:, :, :dqk], dev_qkv[:, :, dqk:2 * dqk], dev_qkv[:, :, 2 * dqk:2 * dqk + dv]
+    o = torch.full((B2, N, dv), float('nan'), dtype=dtype, device=DEV)
+    lse = torch.empty(B2, N, dtype=torch.float32, device=DEV)
+    kk.attn_fwd(qd, kd, vd, o, lse, dqk, dv, B, scale)
+    tol = TOL_T_OUT[dtype]
+    assert rel_err(o, o_ref) <= tol
+    assert float((lse.cpu() - lse_ref.detach()).abs().max()) <= 1e-4
+    dqkv = torch.zeros(B2, N, ld, dtype=dtype, device=DEV)
+    ws = torch.empty(B2 * N, dtype=torch.float32, device=DEV)
+    # backward consumes the STORED (rounded) forward output, as the engine does
+    kk.attn_bwd(qd, kd, vd, o, lse, dqk, dv, B, scale, do.to(dtype).to(DEV), dqkv[:, :, :dqk], dqkv[:, :, dqk:2 * dqk],
+                dqkv[:, :, 2 * dqk:2 * dqk + dv], ws)
+    btol = 2e-4 if dtype == torch.float32 else 2e-2
+    assert rel_err(dqkv[:, :, :dqk], q.grad) <= btol
+    assert rel_err(dqkv[:, :, dqk:2 * dqk], k.grad) <= btol
+    assert rel_err(dqkv[:, :, 2 * dqk:2 * dqk + dv], v.grad) <= btol
+    assert float(dqkv[:, :, 2 * dqk + dv:].float().abs().max()) == 0.0          # padding untouched
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_channel_sum_and_gate_bwd(dtype):
+    """Bias gradient (column sums) and the backward of x + gamma * (W att + b)."""
+    torch.manual_seed(12)
+    rows, C = 1000, 24
+    x = rounded(torch.randn(rows, C + 8), dtype)
+    kk = K()
+    out = torch.empty(C, dtype=torch.float32, device=DEV)
+    ws = torch.empty(kk.channel_sum_workspace_bytes(rows, C) // 4, dtype=torch.float32, device=DEV)
+    kk.channel_sum(x.to(dtype).to(DEV), rows, C, C + 8, out, ws)
+    assert rel_err(out, x[:, :C].sum(0)) <= 1e-5
+    # gate: y = x + gamma * (att @ W^T + b);  given G = dL/dy
+    att = rounded(torch.randn(rows, C), dtype)
+    W = torch.randn(C, C, requires_grad=True)
+    b = torch.randn(C, requires_grad=True)
+    gamma = torch.tensor([0.37], requires_grad=True)
+    att_r = att.clone().requires_grad_(True)
+    G = rounded(torch.randn(rows, C), dtype)
+    (gamma * (att_r @ W.t() + b)).backward(G)
+    t = rounded(G @ W.detach(), dtype)                       # unscaled input gradient of the projection
+    td = t.to(dtype).to(DEV)
+    gsum = G.sum(0).to(DEV)
+    dw = (G.t() @ att).contiguous().to(DEV)                  # wgrad(G, att), unscaled
+    dgamma = torch.empty(1, dtype=torch.float32, device=DEV)
+    dbias = torch.empty(C, dtype=torch.float32, device=DEV)
+    ws2 = torch.empty(1024, dtype=torch.float64, device=DEV)
+    kk.gate_bwd(td, att.to(dtype).to(DEV), gamma.detach().to(DEV), gsum, b.detach().to(DEV), C, dgamma, dbias, dw, ws2)
+    assert rel_err(dgamma, gamma.grad) <= (1e-5 if dtype == torch.float32 else 5e-3)
+    assert rel_err(dbias, b.grad) <= 1e-5
+    assert rel_err(dw, W.grad) <= 1e-5
+    assert rel_err(td, att_r.grad) <= TOL_T_OUT[dtype] * 2
