@@ -44,11 +44,32 @@ class Act:
         self.written = False         # a consumer already wrote .grad in the current backward pass
         self.z = self.mean = self.istd = self.bpart = None
         self.bpart_rows = 0
+        self.alias_of = None         # this record's gradient IS that record's gradient buffer (gated residual)
+        self.pair_data = self.pair_grad = None      # [2B,...] buffers when stacked with a sibling ([left; right])
+
+    def target(self):
+        return self.alias_of if self.alias_of is not None else self
 
     def alloc(self, B, dtype, dev):
-        self.data = torch.empty(B, self.H, self.W, self.C, dtype=dtype, device=dev)
-        if self.needs_grad:
-            self.grad = torch.empty_like(self.data)
+        if self.data is None:
+            self.data = torch.empty(B, self.H, self.W, self.C, dtype=dtype, device=dev)
+        if self.needs_grad and self.grad is None:
+            self.grad = self.alias_of.grad if self.alias_of is not None else torch.empty_like(self.data)
+
+
+def stack_pair(a, b, B, dtype, dev):
+    """Allocate two same-shaped records as the halves of one [2B,H,W,C] buffer (data and gradient), so that ops
+    over [left; right] run as ONE launch with batch 2B."""
+    assert (a.C, a.H, a.W) == (b.C, b.H, b.W)
+    data = torch.empty(2 * B, a.H, a.W, a.C, dtype=dtype, device=dev)
+    a.data, b.data = data[:B], data[B:]
+    a.pair_data = b.pair_data = data
+    if a.alias_of is not None:
+        grad = a.alias_of.pair_grad
+    else:
+        grad = torch.empty_like(data)
+    a.grad, b.grad = grad[:B], grad[B:]
+    a.pair_grad = b.pair_grad = grad
 
 
 class Op:
@@ -181,13 +202,14 @@ class ConvBNReLU(Op):
             return
         segs, epi = [], EPI_ADD
         for s in self.srcs:
+            tgt = s.target()
             if s.fused_bwd:
                 epi = EPI_BWD
                 segs.append(K.Seg(s.C, out0=s.grad, ref=s.data, slope=0.0, z=s.z, mean=s.mean, istd=s.istd,
-                                  partials=s.bpart, accumulate=s.written))
+                                  partials=s.bpart, accumulate=tgt.written))
             else:
-                segs.append(K.Seg(s.C, out0=s.grad if s.needs_grad else eng.scratch_like(s), accumulate=s.written))
-            s.written = True
+                segs.append(K.Seg(s.C, out0=s.grad if s.needs_grad else eng.scratch_like(s), accumulate=tgt.written))
+            tgt.written = True
         K.igemm(T, GEMM_S1, B, o.H, o.W, G, None, self.w_dg, self.c0 + self.c1, epi, segs, eng.workspace, ks=self.ks)
 
 
@@ -256,9 +278,117 @@ class Head1x1(Op):
         eng._ready(self.conv.weight)
 
 
+class CrossAttention(Op):
+    """BinauralCrossAttention.forward (binaural_attention_model.py:106-153) over the stacked pair [left; right]:
+    fused q|k|v 1x1 projection (one GEMM, batch 2B), streaming-softmax attention with kv_shift = B (left attends
+    right and right attends left in one launch), out projection + gated residual x + gamma * out(att) in the
+    GEMM epilogue.  ``xl/xr`` and ``ol/or_`` are stacked pairs; the outputs' gradient buffers alias the inputs'."""
+
+    def __init__(self, xl, xr, mod, ol, or_):
+        self.xl, self.xr, self.mod, self.ol, self.or_ = xl, xr, mod, ol, or_
+        self.out = ol
+        for o in (ol, or_):
+            o.producer = self
+        ol.alias_of, or_.alias_of = xl, xr
+        for x in (xl, xr):
+            x.consumers.append(self)
+
+    def prepare(self, eng):
+        T, dev, B = eng.dtype, eng.dev, eng.B
+        x = self.xl
+        C, H, W = x.C, x.H, x.W
+        m = self.mod
+        self.C, self.dqk = C, m.query.out_channels
+        n_qkv = 2 * self.dqk + C
+        self.ldq = (n_qkv + 63) // 64 * 64 if n_qkv >= 64 else (n_qkv + 7) // 8 * 8
+        f32 = dict(dtype=torch.float32, device=dev)
+        act = lambda c: torch.empty(2 * B, H, W, c, dtype=T, device=dev)
+        self.qkv, self.att, self.tbuf = act(self.ldq), act(C), act(C)
+        self.dqkv = torch.zeros(2 * B, H, W, self.ldq, dtype=T, device=dev)       # padding columns stay zero
+        self.lse = torch.empty(2 * B, H * W, **f32)
+        self.wm_qkv = torch.zeros(self.ldq, C, **f32)                             # fused [q; k; v; 0] master
+        self.b_qkv = torch.zeros(self.ldq, **f32)
+        self.w_qkv = torch.empty(self.ldq, K.s1_row_stride(T, 1, C), dtype=T, device=dev)
+        self.w_qkv_dg = torch.empty(C, K.s1_row_stride(T, 1, self.ldq), dtype=T, device=dev)
+        self.w_out = torch.empty(C, K.s1_row_stride(T, 1, C), dtype=T, device=dev)
+        self.w_out_dg = torch.empty(C, K.s1_row_stride(T, 1, C), dtype=T, device=dev)
+        self.dwm_qkv = torch.empty(self.ldq, C, **f32)
+        self.db_qkv = torch.empty(self.ldq, **f32)
+        self.gsum = torch.empty(C, **f32)
+        q = lambda n, segs, cin: K.igemm_query(T, GEMM_S1, 2 * B, H, W, cin, 0, n, segs, ks=1)[1]
+        rows = 2 * B * H * W
+        self._ws = max(q(self.ldq, [self.ldq], C), q(C, [C], C), q(C, [C], self.ldq),
+                       K.wgrad_workspace_bytes(T, 2 * B, H, W, C, 0, C, 0, ks=1),
+                       K.wgrad_workspace_bytes(T, 2 * B, H, W, self.ldq, 0, C, 0, ks=1),
+                       K.channel_sum_workspace_bytes(rows, max(C, self.ldq)), 8192, rows * 4)
+        self.scale = 1.0 / (C ** 0.5)
+
+    def workspace_bytes(self, eng):
+        return self._ws
+
+    def _slices(self):
+        d, C = self.dqk, self.C
+        return (0, d), (d, 2 * d), (2 * d, 2 * d + C)
+
+    def pack(self, eng):
+        m, C = self.mod, self.C
+        for conv, (lo, hi) in zip((m.query, m.key, m.value), self._slices()):
+            K.pack_rows(eng._flat_slice(eng.flat_p, conv.weight), hi - lo, 1, C, self.wm_qkv[lo:hi])
+            K.pack_rows(eng._flat_slice(eng.flat_p, conv.bias), hi - lo, 1, 1, self.b_qkv[lo:hi])
+        K.pack_rows(self.wm_qkv, self.ldq, 1, C, self.w_qkv)
+        K.pack_transpose_taps(self.wm_qkv, self.ldq, 1, C, self.w_qkv_dg, flip=False)
+        wo = eng._flat_slice(eng.flat_p, m.out.weight)
+        K.pack_rows(wo, C, 1, C, self.w_out)
+        K.pack_transpose_taps(wo, C, 1, C, self.w_out_dg, flip=False)
+
+    def _views(self, buf):
+        N = self.xl.H * self.xl.W
+        flat = buf.view(buf.shape[0], N, buf.shape[-1])
+        return [flat[:, :, lo:hi] for lo, hi in self._slices()]
+
+    def fwd(self, eng, training):
+        T, B, x, m = eng.dtype, eng.B, self.xl, self.mod
+        C, H, W, N = self.C, x.H, x.W, x.H * x.W
+        xin, xout = x.pair_data, self.ol.pair_data
+        K.igemm(T, GEMM_S1, 2 * B, H, W, xin, None, self.w_qkv, self.ldq, EPI_ACT,
+                [K.Seg(self.ldq, out0=self.qkv, bias=self.b_qkv, slope=1.0)], eng.workspace, ks=1)
+        q, k, v = self._views(self.qkv)
+        K.attn_fwd(q, k, v, self.att.view(2 * B, N, C), self.lse, self.dqk, C, B, self.scale)
+        K.igemm(T, GEMM_S1, 2 * B, H, W, self.att, None, self.w_out, C, EPI_ADD,
+                [K.Seg(C, out0=xout, bias=m.out.bias, scale=m.gamma, final_act=1, ref=xin)], eng.workspace, ks=1)
+
+    def bwd(self, eng):
+        T, B, x, m = eng.dtype, eng.B, self.xl, self.mod
+        C, H, W, N = self.C, x.H, x.W, x.H * x.W
+        G = x.pair_grad                      # d loss / d [left_out; right_out] == residual part of d loss / d x
+        assert x.written and self.xr.written
+        fg = lambda p: eng._flat_slice(eng.flat_g, p)
+        ws = eng.workspace
+        K.igemm(T, GEMM_S1, 2 * B, H, W, G, None, self.w_out_dg, C, EPI_ADD, [K.Seg(C, out0=self.tbuf)], ws, ks=1)
+        K.channel_sum(G, 2 * B * N, C, C, self.gsum, ws)
+        K.wgrad(T, 2 * B, H, W, G, None, self.att, None, fg(m.out.weight), ws, ks=1)
+        K.gate_bwd(self.tbuf, self.att, m.gamma, self.gsum, m.out.bias, C, fg(m.gamma), fg(m.out.bias),
+                   fg(m.out.weight), ws)
+        q, k, v = self._views(self.qkv)
+        dq, dk, dv = self._views(self.dqkv)
+        K.attn_bwd(q, k, v, self.att.view(2 * B, N, C), self.lse, self.dqk, C, B, self.scale,
+                   self.tbuf.view(2 * B, N, C), dq, dk, dv, ws)
+        K.wgrad(T, 2 * B, H, W, self.dqkv, None, x.pair_data, None, self.dwm_qkv, ws, ks=1)
+        K.channel_sum(self.dqkv, 2 * B * N, self.ldq, self.ldq, self.db_qkv, ws)
+        for conv, (lo, hi) in zip((m.query, m.key, m.value), self._slices()):
+            K.pack_rows(self.dwm_qkv[lo:hi], hi - lo, 1, C, fg(conv.weight).view(hi - lo, C))
+            K.pack_rows(self.db_qkv[lo:hi], hi - lo, 1, 1, fg(conv.bias))
+        K.igemm(T, GEMM_S1, 2 * B, H, W, self.dqkv, None, self.w_qkv_dg, C, EPI_ADD,
+                [K.Seg(C, out0=G, accumulate=True)], ws, ks=1)
+        eng._mark(m.query.bias, m.key.weight, m.key.bias, m.value.weight, m.value.bias, m.out.weight, m.out.bias,
+                  m.gamma)
+        eng._ready(m.query.weight)
+
+
 class DCEngine(FlatParamEngine):
     """Runs a DoubleConv-family module through libadn.  ``build(engine, B, C, H, W)`` (supplied by the model
-    mirror) returns (input Act, ops, head): the forward op list in execution order and the output head."""
+    mirror) returns (inputs, ops, head): ``inputs`` = [(Act, first channel, channels)] slices of the NCHW network
+    input, the forward op list in execution order, and the output head."""
 
     def __init__(self, module, build, compute_dtype=torch.bfloat16, model_name='model'):
         self.module = module
@@ -288,13 +418,17 @@ class DCEngine(FlatParamEngine):
         self._scratch = {}
         epc = 8 if self.dtype == torch.bfloat16 else 4
         self.epc = epc
-        self.inp, self.ops, self.head = self._build(self, B, Cin, H, W)
+        self.pairs = []
+        self.inputs, self.ops, self.head = self._build(self, B, Cin, H, W)
         acts = {}
         for op in self.ops:
-            for a in list(getattr(op, 'srcs', [])) + [getattr(op, 'src', None), getattr(op, 'out', None)]:
+            for a in (list(getattr(op, 'srcs', [])) +
+                      [getattr(op, k, None) for k in ('src', 'out', 'xl', 'xr', 'ol', 'or_')]):
                 if a is not None:
                     acts[id(a)] = a
         self.acts = list(acts.values())
+        for a, b in self.pairs:                       # inputs of an aliasing pair are stacked before its outputs
+            stack_pair(a, b, B, self.dtype, x.device)
         for a in self.acts:
             prod = a.producer
             a.fused_bwd = (isinstance(prod, ConvBNReLU) and len(a.consumers) == 1 and
@@ -319,14 +453,19 @@ class DCEngine(FlatParamEngine):
         if self.flat_w16 is not None and not self.s2_fresh:
             _lib.record_py(lambda: self.flat_w16.copy_(self.flat_p))
         for op in self.ops:
-            if isinstance(op, ConvBNReLU):
+            if hasattr(op, 'pack'):
                 op.pack(self)
         self.weights_dirty = False
         self.s2_fresh = False
         self._packed_version = self._version_sum()
 
+    def pair(self, a, b):
+        """Stack two records along the batch ([left; right]); call in build() order: inputs before aliases."""
+        self.pairs.append((a, b))
+
     def load_input(self, x):
-        K.nchw_to_nhwc(x, self.inp.data)
+        for act, c_lo, c in self.inputs:
+            K.nchw_slice_to_nhwc(x, c_lo, c, act.data)
 
     def forward(self, x, training):
         if not x.is_cuda:

@@ -190,14 +190,14 @@ def s1_row_stride(dtype, taps, cin):
 def pack_rows(master, X, taps, Y, out, y_pad=None):
     """master f32 [X][taps][Y] -> out [X][row_stride] = [X][taps][y_pad] + zero tail (S1 forward operand)."""
     _dev(master, out)
-    _lib.call('adn_pack_rows', ptr(master), X, taps, Y, Y if y_pad is None else y_pad, out.shape[-1],
-              dtype_code(out.dtype), ptr(out), _stream())
+    _lib.call('adn_pack_rows', ptr(master), X, taps, Y, Y if y_pad is None else y_pad,
+              out.stride(0) if out.dim() > 1 else 1, dtype_code(out.dtype), ptr(out), _stream())
 
 
 def pack_transpose_taps(master, X, taps, Y, out, flip=True):
     """master f32 [X][taps][Y] -> out [Y][row_stride], out[y][t'*X+x] = master[x][t][y] (S1 dgrad operand)."""
     _dev(master, out)
-    _lib.call('adn_pack_transpose_taps', ptr(master), X, taps, Y, int(flip), out.shape[-1], dtype_code(out.dtype),
+    _lib.call('adn_pack_transpose_taps', ptr(master), X, taps, Y, int(flip), out.stride(0), dtype_code(out.dtype),
               ptr(out), _stream())
 
 

@@ -152,7 +152,7 @@ class RGBDepthNet(nn.Module):
             o, d = up.adn_ops(d, feats[3 - i], f'd{4 - i}')
             ops += o
         head = Head1x1(d, self.outc, 0, self.max_depth)
-        return x, ops, head
+        return [(x, 0, 3)], ops, head
 
     def engine(self):
         if self._engine is None or self._engine.dtype != self.compute_dtype:

@@ -208,3 +208,141 @@ def test_rgb_error_behaviour():
         model(torch.rand(1, 2, 64, 64, device=DEV))      # wrong channel count
     with pytest.raises(RuntimeError):
         model.inc(torch.rand(1, 3, 64, 64, device=DEV))  # inner blocks are not callable on their own
+
+
+# ---- BinauralAttentionDepthNet --------------------------------------------------------------------------
+def _binaural(bc, S, dtype, sd=None, max_depth=30.0, levels=(2, 3, 4, 5)):
+    from audio_depth_estimation_amd.models.binaural_attention_model import BinauralAttentionDepthNet
+    model = BinauralAttentionDepthNet(base_channels=bc, bilinear=True, output_size=S, max_depth=max_depth,
+                                      attention_levels=list(levels))
+    model.compute_dtype = dtype
+    if sd is not None:
+        model.load_state_dict(sd)
+    return model.to(DEV)
+
+
+def _noise_bias(k):
+    """Parameters whose true gradient is identically 0, where the reference holds float noise ~1e-9 (and Adam turns
+    that noise into +-lr steps):
+      * fusion conv bias: sits in front of BatchNorm (libadn writes the exact zero);
+      * key bias: shifts every score of a query by the same amount, which softmax ignores;
+      * value / out bias: add a per-channel constant to the attention branch, which passes linearly through the
+        1x1 fusion conv and is removed by its BatchNorm.
+    For the last three libadn, like the reference, ends up with rounding noise."""
+    return ((k.startswith('fusion_layers') and k.endswith('.0.bias')) or
+            (k.startswith('attention_modules') and k.endswith(('.key.bias', '.value.bias', '.out.bias'))))
+
+
+def _check_noise_grad(k, got, scale, rel=1e-4):
+    if k.startswith('fusion_layers'):
+        assert float(got.abs().max()) == 0.0, k
+    else:
+        assert float(got.abs().max()) <= rel * scale, (k, float(got.abs().max()), scale)
+
+
+def _qbias(k):
+    return k.rsplit('.', 2)[0] + '.query.bias'
+
+
+def test_binaural_golden_reference_parity_f32():
+    """tests/golden/binaural64_bc8.npz: two encoders, cross-attention at levels 2-5 (gamma = 0.5), fusion, decoder,
+    sigmoid head; masked (gt > 0) Combined L1 + SIlog loss; AdamW step (train_binaural_attention.py:399-433)."""
+    from audio_depth_estimation_amd.engine import FusedTrainer
+    z = np.load(os.path.join(GOLDEN, 'binaural64_bc8.npz'))
+    bc, S, B = [int(v) for v in z['meta']]
+    lr, wd, max_depth, l1w, sw, lam = [float(v) for v in z['hyper']]
+    sd0 = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('sd0/')}
+    model = _binaural(bc, S, torch.float32, sd0, max_depth)
+    assert list(model.state_dict().keys()) == list(sd0.keys())
+    audio, gt = torch.from_numpy(z['audio']).to(DEV), torch.from_numpy(z['gt']).to(DEV)
+    model.eval()
+    with torch.no_grad():
+        pe = model(audio)
+    assert rel_l1(pe, z['pred_eval']) <= 1e-4
+    model.train()
+    tr = FusedTrainer(model.engine(), 'Combined', l1w, sw, lam, max_depth=max_depth, optimizer='AdamW', lr=lr,
+                      weight_decay=wd, clip_norm=None, mask_mode='gt0')
+    loss, pred = tr.step(audio, gt)
+    assert rel_l1(pred, z['pred_train']) <= 1e-4
+    assert abs(loss.item() - float(z['loss'])) <= 1e-4 * abs(float(z['loss']))
+    assert max_rel(tr.gout, z['pred_grad']) <= 1e-4
+    eng = model.engine()
+    for k, prm in model.named_parameters():
+        if _noise_bias(k):
+            _check_noise_grad(k, eng.grad_view(prm),
+                              float(np.abs(z['grad/' + _qbias(k)]).max()) if k.startswith('attention') else 1.0)
+            continue
+        assert max_rel(eng.grad_view(prm), z['grad/' + k]) <= 3e-3, (k, max_rel(eng.grad_view(prm), z['grad/' + k]))
+    sd1 = model.state_dict()
+    for k in sd1:
+        ref = torch.from_numpy(z['sd1/' + k])
+        if ref.dtype == torch.int64:
+            assert int(sd1[k]) == int(ref), k
+        elif _noise_bias(k):
+            assert float((sd1[k].cpu() - ref).abs().max()) <= 2.02 * lr
+        elif 'grad/' + k in z.files:
+            g = torch.from_numpy(z['grad/' + k]).abs()
+            # |g| at Adam's epsilon scale: the step direction is noise on both sides (up to 2 lr apart)
+            tol = torch.where(g > 1e-6, torch.full_like(g, 0.03 * lr), torch.full_like(g, 2.02 * lr))
+            err = (sd1[k].cpu() - ref).abs()
+            assert bool((err <= tol + 1e-6 * ref.abs()).all()), (k, float(err.max()))
+        else:
+            assert float((sd1[k].cpu() - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-6, k
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_binaural_full_width_against_oracle(dtype):
+    """base_channels=64 at 64x64, B=2 (attention over 1024 / 256 / 64 / 16 tokens): MFMA GEMMs + attention kernels
+    against the float64 oracle.  f32: as for RGBDepthNet.  bf16: the oracle emulates bf16 storage in the conv
+    stacks; this net is ~30 conv/attention stages deep and a freshly initialised BN+ReLU stack amplifies
+    perturbations ~1.7x per stage (see the RGB test), so the end-to-end bf16 bounds can only be loose: prediction
+    relative L1 <= 5e-2 (measured 2.6e-2), gradient cosine >= 0.6 (measured 0.65..1.0).  The f32 path runs the
+    very same templated kernels at 1e-6, and the bf16 kernels are individually bounded in
+    test_gpu_dcnet_kernels.py."""
+    from oracle import dcnet_oracle, loss_oracle
+    torch.manual_seed(0)
+    S = 64
+    model = _binaural(64, S, dtype)
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for m in model.attention_modules.values():
+            m.gamma.fill_(0.5)
+            for conv in (m.query, m.key, m.value, m.out):
+                conv.bias.copy_(0.1 * torch.randn(conv.bias.shape, generator=g))
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    audio = torch.rand(2, 2, S, S, generator=g)
+    gt = 30 * torch.rand(2, 1, S, S, generator=g)
+    gt[gt < 3] = 0
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    pkeys = [k for k, v in sd64.items() if v.is_floating_point() and 'running_' not in k]
+    for k in pkeys:
+        sd64[k].requires_grad_(True)
+    if dtype == torch.bfloat16:
+        dcnet_oracle.QUANT = lambda t: t.float().bfloat16().to(t.dtype)
+    try:
+        pred_ref, stats_ref = dcnet_oracle.binaural_forward(sd64, audio.double(), 30.0, training=True)
+    finally:
+        dcnet_oracle.QUANT = None
+    pred_ref.retain_grad()
+    loss_ref = loss_oracle.masked_loss(pred_ref, gt.double(), 'L1', mask_mode='gt0')
+    loss_ref.backward()
+    model.train()
+    eng = model.engine()
+    f32 = dtype == torch.float32
+    pred = eng.forward(audio.to(DEV), True).clone()
+    assert rel_l1(pred, pred_ref.detach()) <= (1e-5 if f32 else 5e-2)
+    eng.backward(pred_ref.grad.float().to(DEV))
+    for k, prm in model.named_parameters():
+        got = eng.grad_view(prm).detach().float().cpu().reshape(-1)
+        ref = sd64[k].grad.reshape(-1).float()
+        if _noise_bias(k):
+            _check_noise_grad(k, got, float(sd64[_qbias(k)].grad.abs().max()) if k.startswith('attention') else 1.0,
+                              1e-4 if f32 else 5e-2)      # bf16: rounding noise of the summed dk / dv / G rows
+            continue
+        cos = float(torch.dot(got, ref) / (got.norm() * ref.norm() + 1e-30))
+        if f32:
+            rl2 = float((got - ref).norm() / (ref.norm() + 1e-30))
+            assert rl2 <= 2e-2 and cos >= 0.9999, (k, rl2, cos)
+        else:
+            assert cos >= 0.6, (k, cos)
