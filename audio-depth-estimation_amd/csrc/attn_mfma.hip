@@ -1,9 +1,250 @@
-// bf16 MFMA flash-attention kernels for the full-width binaural head dims (placeholder: not yet taken).
+// bf16 MFMA streaming-softmax attention for the full-width binaural head dims (gfx950):
+//   (dqk, dv) in {(16,128), (32,256), (64,512)}  = channels C/8 and C of attention levels 2..5 at base 64,
+//   N a multiple of the query block.  Everything else falls back to the generic kernels of attn.hip.
+//
+// Forward, one workgroup (4 waves) per block of 64*QT queries, 64 keys per iteration:
+//   S^T = K Q^T        v_mfma_f32_16x16x16_bf16, A = K rows (8-byte global loads), B = Q rows held in VGPRs.
+//                      Computing the TRANSPOSE puts, for every lane, 4 consecutive keys of ONE query into the
+//                      accumulator registers -- which is exactly the A-operand register layout of the next MFMA,
+//                      so the probabilities never move between lanes.
+//   P = exp2(S^T * scale*log2e - m)   online max / sum per query (2 xor-shuffles across the 4 lane groups)
+//   O += P V           v_mfma_f32_16x16x32_bf16, A = P (VGPRs), B = V tile staged in LDS by LDS-DMA
+//                      (global_load_lds, double buffered) and read with ds_read_b64_tr_b16 (hardware
+//                      transpose: V is [key][channel] in memory, the MFMA wants channel-major k-slots).
+// LDS V tile: DV/128 panels of [64 keys][128 ch] bf16, 32-byte granules XOR-swizzled by (key & 7) so that the
+// 8 rows a half-wave transposes at once hit 8 different granules (all 64 banks).
 #include "adn_common.h"
 
+namespace {
+
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __attribute__((address_space(3))) s16x4_t* ltr_t;
+
+struct FParams {
+  const uint16_t* q; const uint16_t* k; const uint16_t* v;
+  uint16_t* o; float* lse;
+  int B2, N, shift;
+  int ld_q, ld_k, ld_v, ld_o;
+  float sc2;        // scale * log2(e)
+};
+
+__device__ __forceinline__ int vswz(int row) { return row & 7; }
+
+template <int DQK, int DV, int QT>
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(FParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NP = DV / 128;            // 128-channel panels of the V tile
+  constexpr int PANEL = 64 * 256;         // bytes: 64 keys x 128 ch bf16
+  constexpr int TILE = NP * PANEL;
+  constexpr int KS = DQK / 16;            // k-steps of the score MFMA
+  constexpr int CB = DV / 16;             // 16-channel output blocks
+  extern __shared__ __attribute__((aligned(16))) char smem[];      // [2][TILE]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const int b = blockIdx.y;
+  const int kb = (b + p.shift) % p.B2;
+  const int qbase = blockIdx.x * (64 * QT) + wave * (16 * QT);
+  const uint16_t* Q = p.q + (int64_t)b * p.N * p.ld_q;
+  const uint16_t* Kp = p.k + (int64_t)kb * p.N * p.ld_k;
+  const uint16_t* Vp = p.v + (int64_t)kb * p.N * p.ld_v;
+
+  s16x4_t qf[QT][KS];
+#pragma unroll
+  for (int t = 0; t < QT; ++t)
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+      qf[t][s] = *reinterpret_cast<const s16x4_t*>(Q + (int64_t)(qbase + 16 * t + li) * p.ld_q + 16 * s + 4 * g);
+
+  float m[QT], l[QT];
+  f32x4_t oacc[QT][CB];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    m[t] = -INFINITY;
+    l[t] = 0.f;
+#pragma unroll
+    for (int c = 0; c < CB; ++c) oacc[t][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // V tile staging: per panel 16 wave-writes of 1 KiB (4 rows); wave w, pass j -> rows 16j + 4w .. +3
+  const int vrow = lane >> 4, vpc = lane & 15;
+  auto issue_v = [&](int kt, int buf) {
+#pragma unroll
+    for (int pn = 0; pn < NP; ++pn)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = 16 * j + 4 * wave + vrow;
+        const int lg = (vpc >> 1) ^ vswz(r);
+        const uint16_t* src = Vp + (int64_t)(kt * 64 + r) * p.ld_v + pn * 128 + (lg * 2 + (vpc & 1)) * 8;
+        char* dst = smem + buf * TILE + pn * PANEL + (16 * j + 4 * wave) * 256;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+      }
+  };
+  s16x4_t kf[4][KS];
+  auto load_k = [&](int kt) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+        kf[u][s] = *reinterpret_cast<const s16x4_t*>(Kp + (int64_t)(kt * 64 + 16 * u + li) * p.ld_k + 16 * s + 4 * g);
+  };
+
+  const int nkt = p.N / 64;
+  issue_v(0, 0);
+  load_k(0);
+  const int q4 = li >> 2, pp = li & 3;
+  for (int kt = 0; kt < nkt; ++kt) {
+    // ---- S^T = K Q^T : st[t][u][r] = score(query 16t + li, key 16u + 4g + r)
+    f32x4_t st[QT][4];
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) st[t][u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+          st[t][u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kf[u][s], qf[t][s], st[t][u], 0, 0, 0);
+
+    // ---- online softmax; probabilities packed as the A operand of the PV MFMA
+    bf16x8_t pa[QT][2];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          st[t][u][r] *= p.sc2;
+          mx = fmaxf(mx, st[t][u][r]);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mn = fmaxf(m[t], mx);
+      const float alpha = __builtin_amdgcn_exp2f(m[t] - mn);
+      m[t] = mn;
+      float rs = 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(st[t][u][r] - mn);
+          st[t][u][r] = pv;
+          rs += pv;
+        }
+      rs += __shfl_xor(rs, 16, 64);
+      rs += __shfl_xor(rs, 32, 64);
+      l[t] = l[t] * alpha + rs;
+      // accumulator rows are queries 4g + r; their alpha lives in the lanes with li == 4g + r
+      float ar[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, 4 * g + r, 64);
+#pragma unroll
+      for (int c = 0; c < CB; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) oacc[t][c][r] *= ar[r];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        s16x8_t v8;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v8[r] = (short)f32_to_bf16_bits(st[t][2 * h][r]);
+          v8[4 + r] = (short)f32_to_bf16_bits(st[t][2 * h + 1][r]);
+        }
+        pa[t][h] = *reinterpret_cast<bf16x8_t*>(&v8);
+      }
+    }
+
+    __syncthreads();        // V tile kt has landed (vmcnt(0) in front of the barrier); tile kt-1 is no longer read
+    if (kt + 1 < nkt) {
+      issue_v(kt + 1, (kt + 1) & 1);
+      load_k(kt + 1);
+    }
+
+    // ---- O += P V : k-slot j of lane group g is key 32h + 4g + j (j < 4) / 32h + 16 + 4g + (j - 4)
+    const char* Vb = smem + (kt & 1) * TILE;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int row_lo = 32 * h + 4 * g + q4, row_hi = row_lo + 16;
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        const int pn = cb >> 3, cw = cb & 7;
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (ltr_t)(Vb + pn * PANEL + row_lo * 256 + ((cw ^ vswz(row_lo)) << 5) + pp * 8));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (ltr_t)(Vb + pn * PANEL + row_hi * 256 + ((cw ^ vswz(row_hi)) << 5) + pp * 8));
+        s16x8_t v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const bf16x8_t bfr = *reinterpret_cast<bf16x8_t*>(&v8);
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+          oacc[t][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[t][h], bfr, oacc[t][cb], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: O / l, lse
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    const float inv = 1.f / l[t];
+    float ir[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ir[r] = __shfl(inv, 4 * g + r, 64);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      uint16_t* orow = p.o + ((int64_t)b * p.N + qbase + 16 * t + 4 * g + r) * p.ld_o + li;
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) orow[16 * cb] = f32_to_bf16_bits(oacc[t][cb][r] * ir[r]);
+    }
+    if (g == 0)
+      p.lse[(int64_t)b * p.N + qbase + 16 * t + li] = (m[t] + __log2f(l[t])) * 0.6931471805599453f;
+  }
+#endif
+}
+
+template <int DQK, int DV, int QT>
+void launch_fwd(const FParams& p, hipStream_t st) {
+  constexpr int lds = 2 * (DV / 128) * 64 * 256;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma_kernel<DQK, DV, QT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((attn_fwd_mfma_kernel<DQK, DV, QT>), dim3(p.N / (64 * QT), p.B2), dim3(256), lds, st, p);
+}
+
+bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; }
+
+}  // namespace
+
+// returns 1 when the MFMA kernel took the launch, 0 when the caller must use the generic path
 int adn_attn_mfma_fwd(const AdnAttnDesc* d, hipStream_t st) {
-  (void)d; (void)st;
-  return 0;
+  if (d->dtype != ADN_BF16) return 0;
+  if (getenv("ADN_ATTN_GENERIC")) return 0;
+  int qt;
+  if (d->dqk == 16 && d->dv == 128) qt = 2;
+  else if (d->dqk == 32 && d->dv == 256) qt = 2;
+  else if (d->dqk == 64 && d->dv == 512) qt = 1;
+  else return 0;
+  if (d->N % (64 * qt) != 0) return 0;
+  if ((d->ld_q | d->ld_k | d->ld_v) & 7) return 0;                      // 16-byte rows for the DMA / 8-byte frags
+  if (!aligned16(d->q) || !aligned16(d->k) || !aligned16(d->v)) return 0;
+  FParams p;
+  p.q = reinterpret_cast<const uint16_t*>(d->q);
+  p.k = reinterpret_cast<const uint16_t*>(d->k);
+  p.v = reinterpret_cast<const uint16_t*>(d->v);
+  p.o = reinterpret_cast<uint16_t*>(d->o);
+  p.lse = d->lse;
+  p.B2 = d->B2; p.N = d->N; p.shift = d->kv_shift;
+  p.ld_q = d->ld_q; p.ld_k = d->ld_k; p.ld_v = d->ld_v; p.ld_o = d->ld_o;
+  p.sc2 = d->scale * 1.4426950408889634f;
+  if (d->dqk == 16) launch_fwd<16, 128, 2>(p, st);
+  else if (d->dqk == 32) launch_fwd<32, 256, 2>(p, st);
+  else launch_fwd<64, 512, 1>(p, st);
+  return 1;
 }
 
 int adn_attn_mfma_bwd(const AdnAttnDesc* d, hipStream_t st) {

@@ -362,7 +362,10 @@ def _attn_ref(q, k, v, B, scale):
 
 
 # (B, N, dqk, dv)
-ATTN_SHAPES = [(1, 16, 2, 16), (2, 100, 4, 32), (2, 256, 8, 64), (1, 300, 16, 128), (1, 128, 64, 512)]
+ATTN_SHAPES = [(1, 16, 2, 16), (2, 100, 4, 32), (2, 256, 8, 64), (1, 300, 16, 128), (1, 128, 64, 512),
+               # full-width head dims, N % 128 == 0: the bf16 runs take the MFMA kernels (attn_mfma.hip)
+               (1, 256, 16, 128), (2, 1024, 16, 128), (2, 128, 32, 256), (1, 512, 32, 256), (1, 64, 64, 512),
+               (2, 192, 64, 512)]
 
 
 @pytest.mark.parametrize('dtype', DTYPES)

@@ -55,11 +55,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--only', default=None)
+    ap.add_argument('--attn', action='store_true', help='binaural cross-attention levels instead')
+    ap.add_argument('--bwd', action='store_true')
+    ap.add_argument('--b2', type=int, default=8)
     ap.add_argument('--s1', action='store_true', help='stride-1 3x3 shapes of the DoubleConv nets instead')
     args = ap.parse_args()
     torch.manual_seed(0)
     if args.s1:
         return s1_main(args)
+    if args.attn:
+        return attn_main(args)
     for name, geom, Hs, C0, C1, N in IGEMM:
         if args.only and args.only not in name:
             continue
@@ -119,6 +124,37 @@ def s1_main(args):
         fl = 2.0 * B * H * H * R * 9 * (C0 + C1)
         print(f'{name:15s} M={B*H*H:8d} R={R:4d} C={C0+C1:4d}        {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF/s (incl. slab sum)',
               flush=True)
+
+
+# binaural cross-attention levels at 256x256 input: name, N, dqk, dv (B2 = stacked batch entries)
+ATTN = [('attn_L2', 16384, 16, 128), ('attn_L3', 4096, 32, 256), ('attn_L4', 1024, 64, 512), ('attn_L5', 256, 64, 512)]
+
+
+def attn_main(args):
+    B2 = args.b2
+    for name, N, dqk, dv in ATTN:
+        if args.only and args.only not in name:
+            continue
+        ld = (2 * dqk + dv + 63) // 64 * 64
+        qkv = torch.randn(B2, N, ld, device=DEV).to(T)
+        q, k, v = qkv[:, :, :dqk], qkv[:, :, dqk:2 * dqk], qkv[:, :, 2 * dqk:2 * dqk + dv]
+        o = torch.empty(B2, N, dv, device=DEV, dtype=T)
+        lse = torch.empty(B2, N, device=DEV)
+        sc = 1.0 / dv ** 0.5
+        fn = lambda: K.attn_fwd(q, k, v, o, lse, dqk, dv, B2 // 2, sc)
+        t = timeit(fn, args.iters)
+        fl = 4.0 * B2 * N * N * (dqk + dv)
+        print(f'{name}_fwd B2={B2:3d} N={N:6d} dqk={dqk:3d} dv={dv:4d}  {t*1e6:10.1f} us  {fl/t/1e12:7.1f} TF/s', flush=True)
+        if args.bwd:
+            do = torch.randn(B2, N, dv, device=DEV).to(T)
+            dqkv = torch.zeros(B2, N, ld, device=DEV, dtype=T)
+            ws = torch.empty(B2 * N, device=DEV)
+            fnb = lambda: K.attn_bwd(q, k, v, o, lse, dqk, dv, B2 // 2, sc, do, dqkv[:, :, :dqk], dqkv[:, :, dqk:2 * dqk],
+                                     dqkv[:, :, 2 * dqk:2 * dqk + dv], ws)
+            t = timeit(fnb, args.iters)
+            flb = 2.0 * B2 * N * N * (3 * dqk + 2 * dv)
+            print(f'{name}_bwd B2={B2:3d} N={N:6d} dqk={dqk:3d} dv={dv:4d}  {t*1e6:10.1f} us  {flb/t/1e12:7.1f} TF/s (algorithmic)',
+                  flush=True)
 
 
 if __name__ == '__main__':
