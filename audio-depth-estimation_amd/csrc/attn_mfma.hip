@@ -218,6 +218,377 @@ void launch_fwd(const FParams& p, hipStream_t st) {
 
 bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Backward.  Two kernels, no atomics (deterministic):
+//   dQ  kernel: one workgroup per block of queries, loop over 64-key tiles (structure of the forward):
+//               S^T = K Q^T, dP^T = V dO^T (A = V rows from LDS, B = dO rows in VGPRs), dS^T = P (dP - D) scale,
+//               dQ += dS K (A = dS registers, B = K tile by transpose reads from LDS)
+//   dKV kernel: one workgroup per block of keys, loop over 64-query tiles:
+//               S = Q K^T, dP = dO V^T (A = dO rows from LDS, B = V rows in VGPRs), dV += P^T dO, dK += dS^T Q
+//               (A = P / dS registers, B = dO / Q tiles by transpose reads from LDS)
+// Again each product is oriented so that the accumulator layout of one MFMA is the A-operand layout of the
+// next; the price is that dP is computed in both kernels (1.5x the minimal backward FLOPs for dv >> dqk).
+struct BParams {
+  const uint16_t* q; const uint16_t* k; const uint16_t* v; const uint16_t* dout;
+  const float* lse; const float* dsum;
+  uint16_t* dq; uint16_t* dk; uint16_t* dv;
+  int B2, N, shift;
+  int ld_q, ld_k, ld_v, ld_do, ld_dq, ld_dk, ld_dv;
+  float sc2, scale;
+};
+
+// swizzle of the small [64][DQK] tiles (32-byte granules, DQK/16 granules per row)
+template <int DQK>
+__device__ __forceinline__ int sswz(int row) {
+  return DQK == 16 ? 0 : (DQK == 32 ? ((row >> 2) & 1) : ((row >> 1) & 3));
+}
+
+// stage a [64 rows][DV] bf16 tile (row stride ld elements) into LDS panels with the vswz granule swizzle
+template <int DV>
+__device__ __forceinline__ void stage_wide(const uint16_t* base, int ld, int row0, char* dst_tile, int wave, int lane) {
+  constexpr int NP = DV / 128;
+  constexpr int PANEL = 64 * 256;
+  const int vrow = lane >> 4, vpc = lane & 15;
+#pragma unroll
+  for (int pn = 0; pn < NP; ++pn)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = 16 * j + 4 * wave + vrow;
+      const int lg = (vpc >> 1) ^ vswz(r);
+      const uint16_t* src = base + (int64_t)(row0 + r) * ld + pn * 128 + (lg * 2 + (vpc & 1)) * 8;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst_tile + pn * PANEL + (16 * j + 4 * wave) * 256), 16, 0, 0);
+    }
+}
+
+// stage a [64 rows][DQK] bf16 tile: 64 * DQK * 2 bytes = 2 / 4 / 8 KiB, 1 KiB per wave-write
+template <int DQK>
+__device__ __forceinline__ void stage_narrow(const uint16_t* base, int ld, int row0, char* dst_tile, int wave, int lane) {
+  constexpr int RB = DQK * 2;             // bytes per row
+  constexpr int CPR = RB / 16;            // 16-byte chunks per row
+  constexpr int RPW = 1024 / RB;          // rows per wave-write
+  constexpr int WRITES = 64 / RPW;        // wave-writes per tile: 2 / 4 / 8
+#pragma unroll
+  for (int j = 0; j < (WRITES + 3) / 4; ++j) {
+    const int wi = 4 * j + wave;
+    if (wi < WRITES) {
+      const int r = wi * RPW + lane / CPR, pc = lane % CPR;
+      const int lg = (pc >> 1) ^ sswz<DQK>(r);
+      const uint16_t* src = base + (int64_t)(row0 + r) * ld + (lg * 2 + (pc & 1)) * 8;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst_tile + wi * 1024), 16, 0, 0);
+    }
+  }
+}
+
+__device__ __forceinline__ bf16x8_t pack8(const f32x4_t& a, const f32x4_t& b) {
+  s16x8_t v8;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    v8[r] = (short)f32_to_bf16_bits(a[r]);
+    v8[4 + r] = (short)f32_to_bf16_bits(b[r]);
+  }
+  return *reinterpret_cast<bf16x8_t*>(&v8);
+}
+
+__device__ __forceinline__ bf16x8_t tr_pair(const char* lo_addr, const char* hi_addr) {
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)lo_addr);
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)hi_addr);
+  s16x8_t v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return *reinterpret_cast<bf16x8_t*>(&v8);
+}
+
+template <int DQK, int DV, int QT>
+__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(BParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NP = DV / 128, PANEL = 64 * 256, VT = NP * PANEL, KTB = 64 * DQK * 2;
+  constexpr int KS = DQK / 16, CK = DV / 32, DB = DQK / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];      // [2][VT] V tiles, then [2][KTB] K tiles
+  char* vs = smem;
+  char* ksm = smem + 2 * VT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, li = lane & 15, q4 = li >> 2, pp = li & 3;
+  const int b = blockIdx.y;
+  const int kb = (b + p.shift) % p.B2;
+  const int qbase = blockIdx.x * (64 * QT) + wave * (16 * QT);
+  const uint16_t* Q = p.q + (int64_t)b * p.N * p.ld_q;
+  const uint16_t* DO = p.dout + (int64_t)b * p.N * p.ld_do;
+  const uint16_t* Kp = p.k + (int64_t)kb * p.N * p.ld_k;
+  const uint16_t* Vp = p.v + (int64_t)kb * p.N * p.ld_v;
+
+  s16x4_t qf[QT][KS];
+  bf16x8_t dof[QT][CK];
+  float lse2[QT], dsm[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    const int64_t row = qbase + 16 * t + li;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) qf[t][s] = *reinterpret_cast<const s16x4_t*>(Q + row * p.ld_q + 16 * s + 4 * g);
+#pragma unroll
+    for (int c = 0; c < CK; ++c) dof[t][c] = *reinterpret_cast<const bf16x8_t*>(DO + row * p.ld_do + 32 * c + 8 * g);
+    lse2[t] = p.lse[(int64_t)b * p.N + row] * 1.4426950408889634f;
+    dsm[t] = p.dsum[(int64_t)b * p.N + row];
+  }
+  f32x4_t dqa[QT][DB];
+#pragma unroll
+  for (int t = 0; t < QT; ++t)
+#pragma unroll
+    for (int d = 0; d < DB; ++d) dqa[t][d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  s16x4_t kf[4][KS];
+  auto load_k = [&](int kt) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+        kf[u][s] = *reinterpret_cast<const s16x4_t*>(Kp + (int64_t)(kt * 64 + 16 * u + li) * p.ld_k + 16 * s + 4 * g);
+  };
+  const int nkt = p.N / 64;
+  stage_wide<DV>(Vp, p.ld_v, 0, vs, wave, lane);
+  stage_narrow<DQK>(Kp, p.ld_k, 0, ksm, wave, lane);
+  load_k(0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    f32x4_t st[QT][4];
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) st[t][u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+          st[t][u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kf[u][s], qf[t][s], st[t][u], 0, 0, 0);
+    __syncthreads();
+    if (kt + 1 < nkt) {
+      stage_wide<DV>(Vp, p.ld_v, (kt + 1) * 64, vs + ((kt + 1) & 1) * VT, wave, lane);
+      stage_narrow<DQK>(Kp, p.ld_k, (kt + 1) * 64, ksm + ((kt + 1) & 1) * KTB, wave, lane);
+      load_k(kt + 1);
+    }
+    const char* Vb = vs + (kt & 1) * VT;
+    const char* Kb = ksm + (kt & 1) * KTB;
+    // dP^T = V dO^T : A = V[key 16u + li][32c + 8g ..+7] (16-byte LDS reads), B = dO fragments
+    f32x4_t dp[QT][4];
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) dp[t][u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int row = 16 * u + li;
+#pragma unroll
+      for (int c = 0; c < CK; ++c) {
+        const int pn = c >> 2, gi = 2 * (c & 3) + (g >> 1);
+        const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(Vb + pn * PANEL + row * 256 + ((gi ^ vswz(row)) << 5) + (g & 1) * 16);
+#pragma unroll
+        for (int t = 0; t < QT; ++t) dp[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[t][c], dp[t][u], 0, 0, 0);
+      }
+    }
+    // dS^T = P (dP - D) scale, packed as the A operand (k-slots = keys)
+    bf16x8_t dsa[QT][2];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(st[t][u][r] * p.sc2 - lse2[t]);
+          st[t][u][r] = pv * (dp[t][u][r] - dsm[t]) * p.scale;
+        }
+      dsa[t][0] = pack8(st[t][0], st[t][1]);
+      dsa[t][1] = pack8(st[t][2], st[t][3]);
+    }
+    // dQ += dS K : B[k = key][col = d] by transpose reads of the K tile
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int row_lo = 32 * h + 4 * g + q4, row_hi = row_lo + 16;
+#pragma unroll
+      for (int d = 0; d < DB; ++d) {
+        const bf16x8_t kfr = tr_pair(Kb + row_lo * (DQK * 2) + ((d ^ sswz<DQK>(row_lo)) << 5) + pp * 8,
+                                     Kb + row_hi * (DQK * 2) + ((d ^ sswz<DQK>(row_hi)) << 5) + pp * 8);
+#pragma unroll
+        for (int t = 0; t < QT; ++t) dqa[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsa[t][h], kfr, dqa[t][d], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < QT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      uint16_t* row = p.dq + ((int64_t)b * p.N + qbase + 16 * t + 4 * g + r) * p.ld_dq + li;
+#pragma unroll
+      for (int d = 0; d < DB; ++d) row[16 * d] = f32_to_bf16_bits(dqa[t][d][r]);
+    }
+#endif
+}
+
+template <int DQK, int DV, int KT>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(BParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NP = DV / 128, PANEL = 64 * 256, VT = NP * PANEL, QTB = 64 * DQK * 2;
+  constexpr int KS = DQK / 16, CK = DV / 32, CB = DV / 16, DB = DQK / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];      // [2][VT] dO tiles, then [2][QTB] Q tiles
+  char* dos = smem;
+  char* qsm = smem + 2 * VT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, li = lane & 15, q4 = li >> 2, pp = li & 3;
+  const int kb = blockIdx.y;                                     // batch entry of this key block
+  const int qb = (kb - p.shift + p.B2) % p.B2;                   // the queries attending to it
+  const int kbase = blockIdx.x * (64 * KT) + wave * (16 * KT);
+  const uint16_t* Q = p.q + (int64_t)qb * p.N * p.ld_q;
+  const uint16_t* DO = p.dout + (int64_t)qb * p.N * p.ld_do;
+  const uint16_t* Kp = p.k + (int64_t)kb * p.N * p.ld_k;
+  const uint16_t* Vp = p.v + (int64_t)kb * p.N * p.ld_v;
+  const float* lse = p.lse + (int64_t)qb * p.N;
+  const float* dsum = p.dsum + (int64_t)qb * p.N;
+
+  s16x4_t kfr[KT][KS];        // B operand of S = Q K^T : K[key = li][d = 16s + 4g ..]
+  bf16x8_t vfr[KT][CK];       // B operand of dP = dO V^T : V[key = li][c = 32c + 8g ..]
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+    const int64_t row = kbase + 16 * t + li;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) kfr[t][s] = *reinterpret_cast<const s16x4_t*>(Kp + row * p.ld_k + 16 * s + 4 * g);
+#pragma unroll
+    for (int c = 0; c < CK; ++c) vfr[t][c] = *reinterpret_cast<const bf16x8_t*>(Vp + row * p.ld_v + 32 * c + 8 * g);
+  }
+  f32x4_t dva[KT][CB], dka[KT][DB];
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+#pragma unroll
+    for (int c = 0; c < CB; ++c) dva[t][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int d = 0; d < DB; ++d) dka[t][d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  s16x4_t qf[4][KS];
+  f32x4_t lq[4], dq4[4];
+  auto load_q = [&](int qt) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+        qf[u][s] = *reinterpret_cast<const s16x4_t*>(Q + (int64_t)(qt * 64 + 16 * u + li) * p.ld_q + 16 * s + 4 * g);
+      lq[u] = *reinterpret_cast<const f32x4_t*>(lse + qt * 64 + 16 * u + 4 * g);
+      dq4[u] = *reinterpret_cast<const f32x4_t*>(dsum + qt * 64 + 16 * u + 4 * g);
+    }
+  };
+  const int nqt = p.N / 64;
+  stage_wide<DV>(DO, p.ld_do, 0, dos, wave, lane);
+  stage_narrow<DQK>(Q, p.ld_q, 0, qsm, wave, lane);
+  load_q(0);
+  for (int qt = 0; qt < nqt; ++qt) {
+    // S = Q K^T : st[t][u][r] = score(query 16u + 4g + r, key 16t + li)
+    f32x4_t st[KT][4];
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) st[t][u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+          st[t][u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qf[u][s], kfr[t][s], st[t][u], 0, 0, 0);
+    f32x4_t l2[4], d4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      l2[u] = lq[u] * 1.4426950408889634f;
+      d4[u] = dq4[u];
+    }
+    __syncthreads();
+    if (qt + 1 < nqt) {
+      stage_wide<DV>(DO, p.ld_do, (qt + 1) * 64, dos + ((qt + 1) & 1) * VT, wave, lane);
+      stage_narrow<DQK>(Q, p.ld_q, (qt + 1) * 64, qsm + ((qt + 1) & 1) * QTB, wave, lane);
+      load_q(qt + 1);
+    }
+    const char* Db = dos + (qt & 1) * VT;
+    const char* Qb = qsm + (qt & 1) * QTB;
+    // dP = dO V^T : A = dO[query 16u + li][32c + 8g ..] (16-byte LDS reads), B = V fragments
+    f32x4_t dp[KT][4];
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) dp[t][u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int row = 16 * u + li;
+#pragma unroll
+      for (int c = 0; c < CK; ++c) {
+        const int pn = c >> 2, gi = 2 * (c & 3) + (g >> 1);
+        const bf16x8_t df = *reinterpret_cast<const bf16x8_t*>(Db + pn * PANEL + row * 256 + ((gi ^ vswz(row)) << 5) + (g & 1) * 16);
+#pragma unroll
+        for (int t = 0; t < KT; ++t) dp[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vfr[t][c], dp[t][u], 0, 0, 0);
+      }
+    }
+    bf16x8_t pa[KT][2], dsa[KT][2];
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(st[t][u][r] * p.sc2 - l2[u][r]);
+          st[t][u][r] = pv;
+          dp[t][u][r] = pv * (dp[t][u][r] - d4[u][r]) * p.scale;
+        }
+      pa[t][0] = pack8(st[t][0], st[t][1]);
+      pa[t][1] = pack8(st[t][2], st[t][3]);
+      dsa[t][0] = pack8(dp[t][0], dp[t][1]);
+      dsa[t][1] = pack8(dp[t][2], dp[t][3]);
+    }
+    // dV += P^T dO, dK += dS^T Q : k-slots are queries 32h + 4g + j / 32h + 16 + 4g + (j - 4)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int row_lo = 32 * h + 4 * g + q4, row_hi = row_lo + 16;
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        const int pn = cb >> 3, cw = cb & 7;
+        const bf16x8_t bfr = tr_pair(Db + pn * PANEL + row_lo * 256 + ((cw ^ vswz(row_lo)) << 5) + pp * 8,
+                                     Db + pn * PANEL + row_hi * 256 + ((cw ^ vswz(row_hi)) << 5) + pp * 8);
+#pragma unroll
+        for (int t = 0; t < KT; ++t) dva[t][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[t][h], bfr, dva[t][cb], 0, 0, 0);
+      }
+#pragma unroll
+      for (int d = 0; d < DB; ++d) {
+        const bf16x8_t qfr = tr_pair(Qb + row_lo * (DQK * 2) + ((d ^ sswz<DQK>(row_lo)) << 5) + pp * 8,
+                                     Qb + row_hi * (DQK * 2) + ((d ^ sswz<DQK>(row_hi)) << 5) + pp * 8);
+#pragma unroll
+        for (int t = 0; t < KT; ++t) dka[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsa[t][h], qfr, dka[t][d], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t row = (int64_t)kb * p.N + kbase + 16 * t + 4 * g + r;
+      uint16_t* vrow = p.dv + row * p.ld_dv + li;
+#pragma unroll
+      for (int c = 0; c < CB; ++c) vrow[16 * c] = f32_to_bf16_bits(dva[t][c][r]);
+      uint16_t* krow = p.dk + row * p.ld_dk + li;
+#pragma unroll
+      for (int d = 0; d < DB; ++d) krow[16 * d] = f32_to_bf16_bits(dka[t][d][r]);
+    }
+#endif
+}
+
+template <int DQK, int DV, int QT>
+void launch_bwd(const BParams& p, hipStream_t st) {
+  constexpr int lds = 2 * (DV / 128) * 64 * 256 + 2 * 64 * DQK * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_mfma_kernel<DQK, DV, QT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_mfma_kernel<DQK, DV, QT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  const dim3 grid(p.N / (64 * QT), p.B2);
+  hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<DQK, DV, QT>), grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<DQK, DV, QT>), grid, dim3(256), lds, st, p);
+}
+
 }  // namespace
 
 // returns 1 when the MFMA kernel took the launch, 0 when the caller must use the generic path
@@ -247,7 +618,36 @@ int adn_attn_mfma_fwd(const AdnAttnDesc* d, hipStream_t st) {
   return 1;
 }
 
+
+// d->workspace already holds D = rowsum(dO * O) (attn.hip computes it before calling)
 int adn_attn_mfma_bwd(const AdnAttnDesc* d, hipStream_t st) {
-  (void)d; (void)st;
-  return 0;
+  if (d->dtype != ADN_BF16) return 0;
+  if (getenv("ADN_ATTN_GENERIC")) return 0;
+  int qt;
+  if (d->dqk == 16 && d->dv == 128) qt = 2;
+  else if (d->dqk == 32 && d->dv == 256) qt = 2;
+  else if (d->dqk == 64 && d->dv == 512) qt = 1;
+  else return 0;
+  if (d->N % (64 * qt) != 0) return 0;
+  if ((d->ld_q | d->ld_k | d->ld_v | d->ld_do) & 7) return 0;
+  if (!aligned16(d->q) || !aligned16(d->k) || !aligned16(d->v) || !aligned16(d->dout)) return 0;
+  BParams p;
+  p.q = reinterpret_cast<const uint16_t*>(d->q);
+  p.k = reinterpret_cast<const uint16_t*>(d->k);
+  p.v = reinterpret_cast<const uint16_t*>(d->v);
+  p.dout = reinterpret_cast<const uint16_t*>(d->dout);
+  p.lse = d->lse;
+  p.dsum = reinterpret_cast<const float*>(d->workspace);
+  p.dq = reinterpret_cast<uint16_t*>(d->dq);
+  p.dk = reinterpret_cast<uint16_t*>(d->dk);
+  p.dv = reinterpret_cast<uint16_t*>(d->dvp);
+  p.B2 = d->B2; p.N = d->N; p.shift = d->kv_shift;
+  p.ld_q = d->ld_q; p.ld_k = d->ld_k; p.ld_v = d->ld_v; p.ld_do = d->ld_do;
+  p.ld_dq = d->ld_dq; p.ld_dk = d->ld_dk; p.ld_dv = d->ld_dv;
+  p.sc2 = d->scale * 1.4426950408889634f;
+  p.scale = d->scale;
+  if (d->dqk == 16) launch_bwd<16, 128, 2>(p, st);
+  else if (d->dqk == 32) launch_bwd<32, 256, 2>(p, st);
+  else launch_bwd<64, 512, 1>(p, st);
+  return 1;
 }
