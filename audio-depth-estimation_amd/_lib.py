@@ -63,6 +63,18 @@ class AdnAttnDesc(C.Structure):
     ]
 
 
+class AdnDistillSmall(C.Structure):
+    _fields_ = [
+        ('mean_student', c_void_p), ('mean_teacher', c_void_p), ('centers_student', c_void_p), ('centers_teacher', c_void_p),
+        ('feat_stats', c_void_p * 5), ('feat_channels', c_int32 * 5),
+        ('pix_stats', c_void_p),
+        ('B', c_int32), ('nb', c_int32), ('has_teacher', c_int32),
+        ('temperature', c_float), ('lambda_task', c_float), ('lambda_response', c_float), ('lambda_feature', c_float),
+        ('lambda_bin', c_float), ('lambda_sparse', c_float),
+        ('terms', c_void_p), ('dmean', c_void_p), ('dcent', c_void_p),
+    ]
+
+
 # name -> (restype, argtypes).  Must list every symbol include/adn.h declares
 # (tests/test_abi.py cross-checks this table against the header and the built library).
 _PROTOS = {
@@ -100,6 +112,21 @@ _PROTOS = {
     'adn_channel_sum': (C.c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
     'adn_gate_bwd': (C.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                c_void_p]),
+    'adn_pool_workspace_bytes': (c_int64, [c_int32, c_int32, c_int32, c_int32]),
+    'adn_pool': (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p, c_int64, c_void_p]),
+    'adn_binpred_fwd': (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                  c_void_p]),
+    'adn_binpred_bwd': (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_float, c_float, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_void_p]),
+    'adn_dropout_mask': (C.c_int, [c_void_p, c_int64, c_float, C.c_uint64, c_void_p]),
+    'adn_bcast_add': (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_int32, c_int32, c_void_p]),
+    'adn_bins_fwd': (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    'adn_bins_bwd_workspace_bytes': (c_int64, [c_int32, c_int32, c_int32]),
+    'adn_bins_bwd': (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_void_p]),
+    'adn_distill_pix_stats': (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    'adn_distill_pix_grad': (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    'adn_featcos_grad': (C.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p]),
+    'adn_distill_small': (C.c_int, [C.POINTER(AdnDistillSmall), c_void_p]),
     'adn_nhwc_to_nchw': (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     'adn_bn_fwd_finalize': (C.c_int, [c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p, c_float, c_float,
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -1,0 +1,400 @@
+"""AdaBins distillation model on libadn: two DoubleConv op tapes (RGB teacher, audio student), the bin predictor,
+the soft-binning head, the residual head and the fused distillation step.
+
+Replaces what PyTorch dispatches for /root/reference/models/adabins_distillation_model.py:301-426 and the training
+step of /root/reference/train_adabins_distillation.py:445-456 with utils_distillation_loss.DistillationLoss
+(:147-238).  Data layout as in dc_engine.py; additionally per branch: pooled bottleneck g [B,512] f32, hidden
+activations / bin widths / centres f32, bin logits [B,H,W,n_bins] in the compute dtype (never expanded to
+f32 NCHW unless the caller asks for ``bin_logits``), base depth / residual / final depth f32 [B,1,H,W].
+The teacher's parameters are a contiguous prefix of the flat parameter buffer (parameters() order); it never
+receives gradients (the reference runs it under no_grad), so the clip norm and the optimizer act on the suffix.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from . import kernels as K
+from .dc_engine import Act, ConvBNReLU, DCEngine, Head1x1, Op
+from ._lib import EPI_ACT, EPI_ADD, GEMM_S1
+
+
+class ConvLinear(Op):
+    """Conv2d 1x1 with bias, no norm / activation (the class head, adabins_distillation_model.py:192)."""
+
+    def __init__(self, src, conv, out):
+        self.src, self.conv, self.out = src, conv, out
+        out.producer = self
+        src.consumers.append(self)
+
+    def prepare(self, eng):
+        T, dev, B = eng.dtype, eng.dev, eng.B
+        s, o = self.src, self.out
+        self.w_fwd = torch.empty(o.C, K.s1_row_stride(T, 1, s.C), dtype=T, device=dev)
+        self.w_dg = torch.empty(s.C, K.s1_row_stride(T, 1, o.C), dtype=T, device=dev) if s.needs_grad else None
+        q = lambda n, segs, cin: K.igemm_query(T, GEMM_S1, B, o.H, o.W, cin, 0, n, segs, ks=1)[1]
+        self._ws = max(q(o.C, [o.C], s.C), q(s.C, [s.C], o.C) if s.needs_grad else 0,
+                       K.wgrad_workspace_bytes(T, B, o.H, o.W, o.C, 0, s.C, 0, ks=1),
+                       K.channel_sum_workspace_bytes(B * o.H * o.W, o.C))
+
+    def workspace_bytes(self, eng):
+        return self._ws
+
+    def pack(self, eng):
+        master = eng._flat_slice(eng.flat_p, self.conv.weight)
+        K.pack_rows(master, self.out.C, 1, self.src.C, self.w_fwd)
+        if self.w_dg is not None:
+            K.pack_transpose_taps(master, self.out.C, 1, self.src.C, self.w_dg, flip=False)
+
+    def fwd(self, eng, training):
+        o = self.out
+        K.igemm(eng.dtype, GEMM_S1, eng.B, o.H, o.W, self.src.data, None, self.w_fwd, o.C, EPI_ACT,
+                [K.Seg(o.C, out0=o.data, bias=self.conv.bias, slope=1.0)], eng.workspace, ks=1)
+
+    def bwd(self, eng):
+        o, s = self.out, self.src
+        fg = lambda p: eng._flat_slice(eng.flat_g, p)
+        K.wgrad(eng.dtype, eng.B, o.H, o.W, o.grad, None, s.data, None, fg(self.conv.weight), eng.workspace, ks=1)
+        K.channel_sum(o.grad, eng.B * o.H * o.W, o.C, o.C, fg(self.conv.bias), eng.workspace)
+        K.igemm(eng.dtype, GEMM_S1, eng.B, o.H, o.W, o.grad, None, self.w_dg, s.C, EPI_ADD,
+                [K.Seg(s.C, out0=s.grad, accumulate=s.written)], eng.workspace, ks=1)
+        s.written = True
+
+
+class BinPredictor(Op):
+    """AdaBinsBinPredictor.forward (:127-149) placed right behind the producer of x5 in the tape, so that in the
+    reversed tape its backward runs after every other consumer of x5 and before x5's own backward."""
+
+    def __init__(self, x5, mod, branch):
+        self.src, self.mod, self.branch = x5, mod, branch
+        self.out = x5                       # (tape bookkeeping: backward runs iff x5 needs a gradient)
+        x5.consumers.append(self)
+
+    def prepare(self, eng):
+        B, dev = eng.B, eng.dev
+        x = self.src
+        lin1, lin2 = self.mod.predictor[0], self.mod.predictor[3]
+        self.Cb, self.Hd, self.nb = lin1.in_features, lin1.out_features, lin2.out_features
+        self.p = float(self.mod.predictor[2].p)
+        f32 = dict(dtype=torch.float32, device=dev)
+        br = self.branch
+        br.g = torch.empty(B, self.Cb, **f32)
+        br.h1 = torch.empty(B, self.Hd, **f32)
+        br.widths, br.centers = torch.empty(B, self.nb, **f32), torch.empty(B, self.nb, **f32)
+        self.mask = torch.empty(B, self.Hd, dtype=torch.uint8, device=dev)
+        if x.needs_grad:
+            self.dW2p = torch.empty(B, self.nb * self.Hd, **f32)
+            self.db2p = torch.empty(B, self.nb, **f32)
+            self.dW1p = torch.empty(B, self.Hd * self.Cb, **f32)
+            self.db1p = torch.empty(B, self.Hd, **f32)
+            self.dg = torch.empty(B, self.Cb, **f32)
+            br.dcent = torch.empty(B, self.nb, **f32)
+        self._ws = max(K.pool_workspace_bytes(B, x.H * x.W, x.C, 1), K.channel_sum_workspace_bytes(B, self.Hd * self.Cb))
+        self.draws = 0
+
+    def workspace_bytes(self, eng):
+        return self._ws
+
+    def _params(self, eng):
+        lin1, lin2 = self.mod.predictor[0], self.mod.predictor[3]
+        fp = lambda p: eng._flat_slice(eng.flat_p, p)
+        return fp(lin1.weight).view(self.Hd, self.Cb), fp(lin1.bias), fp(lin2.weight).view(self.nb, self.Hd), fp(lin2.bias)
+
+    def fwd(self, eng, training):
+        x, br = self.src, self.branch
+        K.pool(x.data, None, eng.B, x.H * x.W, x.C, 1, 1.0 / (x.H * x.W), br.g, eng.workspace)
+        self.use_mask = bool(training and self.p > 0.0)
+        if self.use_mask:
+            self.draws += 1
+            K.dropout_mask(self.mask, self.p, eng.dropout_seed * 1000003 + self.draws * 2 + br.index)
+        W1, b1, W2, b2 = self._params(eng)
+        K.binpred_fwd(br.g, W1, b1, W2, b2, self.mask if self.use_mask else None, self.p, self.mod.max_depth, br.h1,
+                      br.widths, br.centers)
+
+    def bwd(self, eng):
+        x, br = self.src, self.branch
+        W1, _, W2, _ = self._params(eng)
+        lin1, lin2 = self.mod.predictor[0], self.mod.predictor[3]
+        K.binpred_bwd(br.dcent, br.widths, br.h1, br.g, W1, W2, self.use_mask, self.p, self.mod.max_depth, self.dW2p,
+                      self.db2p, self.dW1p, self.db1p, self.dg)
+        fg = lambda p: eng._flat_slice(eng.flat_g, p)
+        B = eng.B
+        for part, prm in ((self.dW2p, lin2.weight), (self.db2p, lin2.bias), (self.dW1p, lin1.weight), (self.db1p, lin1.bias)):
+            n = part.shape[1]
+            K.channel_sum(part, B, n, n, fg(prm), eng.workspace)
+        K.bcast_add(x.grad, self.dg, 1.0 / (x.H * x.W), accumulate=x.written)
+        x.written = True
+
+
+class FeatureLoss(Op):
+    """Gradient of the feature-distillation term (utils_distillation_loss.py:72-98) into an encoder activation; sits
+    right behind that activation's producer in the tape (see BinPredictor)."""
+
+    def __init__(self, act, level, eng):
+        self.src, self.out, self.level = act, act, level
+        act.consumers.append(self)
+
+    def fwd(self, eng, training):
+        pass
+
+    def bwd(self, eng):
+        if eng.feat_coef is None:
+            return
+        a = self.src
+        assert a.written
+        t = eng.branches['rgb'].feats[self.level]
+        K.featcos_grad(a.data, t.data, eng.feat_stats[self.level], eng.feat_coef[self.level], a.grad)
+
+
+class _Branch:
+    pass
+
+
+class AdaBinsEngine(DCEngine):
+    """Runs AdaBinsDistillationModel through libadn (one engine per module instance)."""
+
+    def __init__(self, module, compute_dtype=torch.bfloat16):
+        super().__init__(module, None, compute_dtype, 'AdaBinsDistillationModel')
+        self.dropout_seed = 0
+        self.feat_coef = None
+        self.feat_stats = None
+        self.branches = {}
+
+    # ------------------------------------------------------------------ build
+    def _build_branch(self, name, index, Cin, enc, pred, dec, B, H, W, needs_grad):
+        m = self.module
+        br = _Branch()
+        br.name, br.index, br.needs_grad = name, index, needs_grad
+        br.inp = self.thin_input(name + '.in', Cin, H, W)
+        ops_e, feats = enc.adn_ops(br.inp, name, H, W)
+        ops = []
+        for op in ops_e:                                # feature-loss / bin-predictor hooks right behind the producers
+            ops.append(op)
+            for lv, f in enumerate(feats):
+                if getattr(op, 'out', None) is f and isinstance(op, ConvBNReLU):
+                    if needs_grad:
+                        ops.append(FeatureLoss(f, lv, self))
+                    if lv == 4:
+                        ops.append(BinPredictor(f, pred, br))
+        ops_d, d1 = dec.adn_ops(feats, name)
+        br.dec_bn_ops = [op for op in ops_d if isinstance(op, ConvBNReLU)]
+        ops += ops_d
+        br.logits = Act(name + '.logits', dec.n_bins, H, W)
+        br.class_op = ConvLinear(d1, dec.class_head, br.logits)
+        br.head = Head1x1(d1, m.residual_head, 2, 0.05 * m.max_depth)
+        br.ops, br.feats, br.d1 = ops, feats, d1
+        if not needs_grad:
+            for op in ops + [br.class_op]:
+                for a in list(getattr(op, 'srcs', [])) + [getattr(op, 'src', None), getattr(op, 'out', None)]:
+                    if a is not None:
+                        a.needs_grad = False
+        return br
+
+    def _prepare_branches(self, B, H, W, dev):
+        if not self._bound():
+            self.bind_parameters()
+        key = (B, H, W, dev)
+        if key == self._shape_key:
+            return
+        m = self.module
+        if H != m.output_size or W != m.output_size:
+            raise NotImplementedError(f'input {H}x{W} != output_size {m.output_size}: the nearest-neighbour resize of the '
+                                      'logits (reference :194-196) is not on the libadn path')
+        self.B, self.dev = B, dev
+        self._scratch = {}
+        self.epc = 8 if self.dtype == torch.bfloat16 else 4
+        self.pairs = []
+        self.branches = {
+            'rgb': self._build_branch('rgb', 0, 3, m.rgb_encoder, m.rgb_bin_predictor, m.rgb_decoder, B, H, W, False),
+            'audio': self._build_branch('audio', 1, 2, m.audio_encoder, m.audio_bin_predictor, m.audio_decoder, B, H, W,
+                                        True),
+        }
+        f32 = dict(dtype=torch.float32, device=dev)
+        ws = 1 << 16
+        self.ops = []
+        for br in self.branches.values():
+            allops = br.ops + [br.class_op]
+            acts = {}
+            for op in allops:
+                for a in list(getattr(op, 'srcs', [])) + [getattr(op, 'src', None), getattr(op, 'out', None)]:
+                    if a is not None:
+                        acts[id(a)] = a
+            br.acts = list(acts.values())
+            for a in br.acts:
+                prod = a.producer
+                a.fused_bwd = (a.needs_grad and isinstance(prod, ConvBNReLU) and len(a.consumers) == 1 and
+                               isinstance(a.consumers[0], ConvBNReLU) and len(a.consumers[0].srcs) == 1)
+                a.alloc(B, self.dtype, dev)
+            for op in allops + [br.head]:
+                op.prepare(self)
+                ws = max(ws, op.workspace_bytes(self))
+            self.ops += allops                           # (weight packing walks self.ops)
+            pix = B * H * W
+            br.base = torch.empty(pix, **f32)
+            br.final = torch.empty(B, 1, H, W, **f32)
+            br.mean_logits = torch.empty(B, m.n_bins, **f32)
+            ws = max(ws, K.pool_workspace_bytes(B, H * W, m.n_bins, 1), K.bins_bwd_workspace_bytes(B, H * W, m.n_bins))
+            for f in br.feats:
+                ws = max(ws, K.pool_workspace_bytes(B, f.H * f.W, f.C, 3))
+        st = self.branches['audio']
+        st.dbase, st.dres = torch.empty(B * H * W, **f32), torch.empty(B * H * W, **f32)
+        st.dmean, st.dcent_extra = torch.empty(B, m.n_bins, **f32), torch.empty(B, m.n_bins, **f32)
+        self.feat_stats_buf = [torch.empty(B, 3, f.C, **f32) for f in st.feats]
+        self.pix_stats = torch.zeros(4, dtype=torch.float64, device=dev)
+        self.terms = torch.zeros(8, **f32)
+        self.workspace = torch.empty(ws // 4 + 4, **f32)
+        self.weights_dirty = True
+        self._shape_key = key
+        # the teacher's parameters are a prefix of parameters(): first trainable offset
+        first = next(iter(m.audio_encoder.parameters()))
+        self.train_offset = self.offset[id(first)]
+
+    # ------------------------------------------------------------------ forward of one branch
+    def _forward_branch(self, br, x, training):
+        if not x.is_cuda:
+            raise RuntimeError('AdaBinsDistillationModel needs HIP device tensors (libadn has no CPU path)')
+        x = x.contiguous().float()
+        want = 3 if br.name == 'rgb' else 2
+        if x.shape[1] != want:
+            raise RuntimeError(f'expected input[{list(x.shape)}] to have {want} channels, but got {x.shape[1]} channels instead')
+        self._prepare_branches(x.shape[0], x.shape[2], x.shape[3], x.device)
+        if self.weights_dirty or self._packed_version != self._version_sum():
+            self._pack_weights()
+        K.nchw_slice_to_nhwc(x, 0, want, br.inp.data)
+        for op in br.ops:
+            op.fwd(self, training)
+        if training:                                    # the reference's second decoder pass: same activations, but
+            for op in br.dec_bn_ops:                    # every decoder BatchNorm updates its running stats once more
+                op.update_running_stats_again(self)
+        br.class_op.fwd(self, training)
+        K.bins_fwd(br.logits.data, br.centers, br.base)
+        br.head.fwd(self, training)
+
+    def _finalize_plain(self, br):
+        """final = clamp(base + residual) without loss terms (gt := base only feeds statistics nobody reads)."""
+        K.distill_pix_stats(br.base, br.head.result, br.base, None, self.module.max_depth, br.final, self.pix_stats,
+                            self.workspace)
+
+    def run_branch(self, which, x, training):
+        br_name = 'rgb' if which == 'rgb' else 'audio'
+        with torch.no_grad():
+            self._prepare_branches(x.shape[0], x.shape[2], x.shape[3], x.device)
+            br = self.branches[br_name]
+            self._forward_branch(br, x, training)
+            self._finalize_plain(br)
+            return self._outputs(br)
+
+    def _outputs(self, br):
+        B, m = self.B, self.module
+        feats = {}
+        for i, f in enumerate(br.feats):
+            t = torch.empty(B, f.C, f.H, f.W, dtype=torch.float32, device=self.dev)
+            K.nhwc_to_nchw(f.data, t)
+            feats[f'x{i + 1}'] = t
+        lg = br.logits
+        logits = torch.empty(B, lg.C, lg.H, lg.W, dtype=torch.float32, device=self.dev)
+        K.nhwc_to_nchw(lg.data, logits)
+        shp = (B, 1, lg.H, lg.W)
+        return {'features': feats, 'bin_centers': br.centers.clone(), 'bin_widths': br.widths.clone(), 'bin_logits': logits,
+                'base_depth': br.base.view(shp).clone(), 'residual': br.head.result.view(shp).clone(),
+                'final_depth': br.final.clone()}
+
+    # ------------------------------------------------------------------ backward of the student
+    def backward_student(self, dbase, dres, dmean, dcent_extra):
+        br = self.branches['audio']
+        for a in br.acts:
+            a.written = False
+        self._final = set(id(p) for p, _, _ in self.param_meta if not p.requires_grad)
+        self._wm = len(self.param_meta)
+        br.head.bwd_head(self, dres)
+        K.bins_bwd(br.logits.data, br.centers, br.base, dbase, dmean, br.logits.grad, br.dcent, self.workspace)
+        if dcent_extra is not None:
+            K.bcast_add(br.dcent.view(self.B, 1, 1, -1), dcent_extra, 1.0, accumulate=True)
+        br.class_op.bwd(self)
+        for op in reversed(br.ops):
+            if op.out.needs_grad:
+                op.bwd(self)
+
+
+def _update_again(self, eng):
+    """Second running-statistics update of a decoder BatchNorm with the same batch statistics."""
+    bn, o = self.bn, self.out
+    track = bn.track_running_stats and bn.running_mean is not None
+    if not track:
+        return
+    K.bn_fwd_finalize(self.part, self.P, self.N, eng.B * o.H * o.W, bn.weight, bn.bias, bn.eps,
+                      0.1 if bn.momentum is None else bn.momentum, bn.running_mean, bn.running_var,
+                      bn.num_batches_tracked, o.mean, o.istd, self.scale, self.shift)
+
+
+ConvBNReLU.update_running_stats_again = _update_again
+
+
+class AdaBinsTrainer:
+    """One fused distillation step: teacher forward, student forward, DistillationLoss, student backward,
+    clip_grad_norm_(1.0), AdamW -- train_adabins_distillation.py:445-456 with the loss weights of :179-188."""
+
+    def __init__(self, engine, lambda_task=1.0, lambda_response=0.5, lambda_feature=0.3, lambda_bin=0.2,
+                 lambda_sparse=0.1, temperature=4.0, optimizer='AdamW', lr=1e-4, betas=(0.9, 0.999), eps=1e-8,
+                 weight_decay=None, clip_norm=1.0):
+        self.engine = engine
+        self.lambdas = (lambda_task, lambda_response, lambda_feature, lambda_bin, lambda_sparse)
+        self.temperature = temperature
+        self.opt_kind = {'AdamW': 0, 'Adam': 1, 'SGD': 2}[optimizer]
+        self.lr, self.betas, self.eps = float(lr), betas, float(eps)
+        self.weight_decay = float((0.01 if optimizer == 'AdamW' else 0.0) if weight_decay is None else weight_decay)
+        self.clip_norm = clip_norm
+        self._ready = False
+
+    def _setup(self, dev):
+        eng = self.engine
+        f64 = dict(dtype=torch.float64, device=dev)
+        self.state = torch.zeros(8, **f64)
+        self.norm_ws = torch.empty(1024 + 8, **f64)
+        self.exp_avg = torch.zeros_like(eng.flat_p)
+        self.exp_avg_sq = torch.zeros_like(eng.flat_p)
+        self._ready = True
+
+    def step(self, audio, rgb, gt):
+        """audio [B,2,H,W], rgb [B,3,H,W] or None, gt [B,1,H,W] -> (total loss 0-dim device tensor, terms f32[8])."""
+        eng = self.engine
+        m = eng.module
+        eng._prepare_branches(audio.shape[0], audio.shape[2], audio.shape[3], audio.device)
+        if not self._ready:
+            self._setup(audio.device)
+        st, te = eng.branches['audio'], eng.branches['rgb']
+        gt = gt.contiguous().float()
+        has_t = rgb is not None
+        if has_t:
+            eng._forward_branch(te, rgb, True)
+            eng._finalize_plain(te)
+        eng._forward_branch(st, audio, True)
+        lt, lr_, lf, lb, ls = self.lambdas
+        K.distill_pix_stats(st.base, st.head.result, gt, te.final if has_t else None, m.max_depth, st.final,
+                            eng.pix_stats, eng.workspace)
+        B, HW = eng.B, st.logits.H * st.logits.W
+        K.pool(st.logits.data, None, B, HW, m.n_bins, 1, 1.0 / HW, st.mean_logits, eng.workspace)
+        if has_t:
+            K.pool(te.logits.data, None, B, HW, m.n_bins, 1, 1.0 / HW, te.mean_logits, eng.workspace)
+            for i, (a, r) in enumerate(zip(st.feats, te.feats)):
+                K.pool(a.data, r.data, B, a.H * a.W, a.C, 3, 1.0, eng.feat_stats_buf[i], eng.workspace)
+            eng.feat_stats = eng.feat_stats_buf
+            eng.feat_coef = [-lf / (5.0 * B * a.C) for a in st.feats]
+        else:
+            eng.feat_stats, eng.feat_coef = None, None
+        K.distill_small(st.mean_logits, te.mean_logits if has_t else None, st.centers, te.centers if has_t else None,
+                        eng.feat_stats_buf, [a.C for a in st.feats], eng.pix_stats, self.temperature, self.lambdas,
+                        eng.terms, st.dmean, st.dcent_extra)
+        K.distill_pix_grad(st.base, st.head.result, gt, te.final if has_t else None, m.max_depth, eng.pix_stats, lt,
+                           lr_ if has_t else 0.0, ls, st.dbase, st.dres)
+        eng.backward_student(st.dbase, st.dres, st.dmean, st.dcent_extra)
+        off = eng.train_offset
+        p, g = eng.flat_p[off:], eng.flat_g[off:]
+        if self.clip_norm is not None:
+            K.grad_norm(g, float(self.clip_norm), self.state, self.norm_ws)
+        K.optimizer_step(p, g, self.exp_avg[off:], self.exp_avg_sq[off:], self.opt_kind, self.lr, self.betas[0],
+                         self.betas[1], self.eps, self.weight_decay, self.clip_norm is not None, self.state,
+                         bf16_copy=eng.flat_w16[off:] if eng.flat_w16 is not None else None)
+        eng.weights_dirty = True
+        eng.s2_fresh = False            # the teacher half of the bf16 mirror is still valid, but keep the re-cast simple
+        return eng.terms[6], eng.terms

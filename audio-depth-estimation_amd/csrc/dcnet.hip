@@ -330,8 +330,12 @@ __global__ __launch_bounds__(256) void head1x1_fwd_kernel(const T* x, const floa
     if (pix < pixels && lig == 0) {
       const float zz = s + b;
       zpre[pix] = zz;
-      float o_ = act == 1 ? maxd / (1.f + __expf(-zz)) : zz;
-      out[pix] = fminf(fmaxf(o_, 0.f), maxd);
+      if (act == 2) {
+        out[pix] = tanhf(zz) * maxd;
+      } else {
+        float o_ = act == 1 ? maxd / (1.f + __expf(-zz)) : zz;
+        out[pix] = fminf(fmaxf(o_, 0.f), maxd);
+      }
     }
   }
 }
@@ -361,6 +365,9 @@ __global__ __launch_bounds__(256) void head1x1_bwd_kernel(const float* gout, con
     if (act == 1) {
       const float s = 1.f / (1.f + __expf(-zz));
       d = maxd * s * (1.f - s);
+    } else if (act == 2) {
+      const float t = tanhf(zz);
+      d = maxd * (1.f - t * t);
     } else {
       d = (zz >= 0.f && zz <= maxd) ? 1.f : 0.f;
     }
@@ -613,7 +620,7 @@ extern "C" int adn_head1x1_fwd(const void* x, const float* w, const float* bias,
                                int32_t dtype, int32_t act, float max_depth, float* zpre, float* out, void* stream) {
   ADN_CHECK_ARG(x && w && zpre && out && pixels > 0 && C > 0, "adn_head1x1_fwd: bad arguments");
   ADN_CHECK_ARG(dtype == ADN_F32 || dtype == ADN_BF16, "adn_head1x1_fwd: bad dtype %d", dtype);
-  ADN_CHECK_ARG(act == 0 || act == 1, "adn_head1x1_fwd: bad act %d", act);
+  ADN_CHECK_ARG(act >= 0 && act <= 2, "adn_head1x1_fwd: bad act %d", act);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int V = (C & 7) == 0 ? 8 : 1;
   const int lpp = head_lpp(C, V);
@@ -643,7 +650,7 @@ extern "C" int adn_head1x1_bwd(const float* gout, const float* zpre, const void*
                                void* workspace, int64_t workspace_bytes, void* stream) {
   ADN_CHECK_ARG(gout && zpre && x && w && gx && dw && pixels > 0 && C > 0, "adn_head1x1_bwd: bad arguments");
   ADN_CHECK_ARG(dtype == ADN_F32 || dtype == ADN_BF16, "adn_head1x1_bwd: bad dtype %d", dtype);
-  ADN_CHECK_ARG(act == 0 || act == 1, "adn_head1x1_bwd: bad act %d", act);
+  ADN_CHECK_ARG(act >= 0 && act <= 2, "adn_head1x1_bwd: bad act %d", act);
   const int V = (C & 7) == 0 ? 8 : 1;
   const int lpp = head_lpp(C, V);
   ADN_CHECK_ARG(C <= lpp * V * kHeadIt, "adn_head1x1_bwd: C = %d too large (max %d)", C, lpp * V * kHeadIt);

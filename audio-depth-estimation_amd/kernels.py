@@ -10,7 +10,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import AdnAttnDesc  # noqa: E402
+from ._lib import AdnAttnDesc, AdnDistillSmall  # noqa: E402
 from ._lib import (ADN_BF16, ADN_F32, EPI_ACT, EPI_ADD, EPI_BWD, EPI_FINAL, EPI_RAW, EPI_Z_STATS, GEMM_S1, GEMM_S2, GEMM_T2,
                    AdnEpiSeg, AdnIgemmDesc, AdnWgradDesc, ptr)
 
@@ -467,3 +467,101 @@ def gate_bwd(t, att, gamma, gsum, bias, Cc, dgamma, dbias, dw, workspace):
     _lib.call('adn_gate_bwd', ptr(t), ptr(att), t.numel(), dtype_code(t.dtype), ptr(gamma), ptr(gsum), ptr(bias), Cc,
               ptr(dgamma), ptr(dbias), ptr(dw), dw.numel() if dw is not None else 0, ptr(workspace),
               workspace.numel() * workspace.element_size(), _stream())
+
+
+# ---- AdaBins distillation model (csrc/adabins.hip) -----------------------------------------------------------
+def _nbytes(t):
+    return t.numel() * t.element_size()
+
+
+def pool_workspace_bytes(B, HW, Cc, nq=1):
+    return _lib.load().adn_pool_workspace_bytes(B, HW, Cc, nq)
+
+
+def pool(x, y, B, HW, Cc, nq, scale, out, workspace):
+    """x (and y) [B,HW,Cc] NHWC views -> out f32 [B,Cc] (nq=1: scale*sum x) or [B,3,Cc] (sum x^2, y^2, x*y)."""
+    _dev(x, y, out, workspace)
+    _lib.call('adn_pool', ptr(x), ptr(y), B, HW, Cc, x.shape[-1], nq, dtype_code(x.dtype), float(scale), ptr(out),
+              ptr(workspace), _nbytes(workspace), _stream())
+
+
+def binpred_fwd(g, W1, b1, W2, b2, mask, drop_p, max_depth, h1, widths, centers):
+    B, Cb = g.shape
+    Hd, nb = W1.shape[0], W2.shape[0]
+    _dev(g, W1, b1, W2, b2, mask, h1, widths, centers)
+    _lib.call('adn_binpred_fwd', ptr(g), ptr(W1), ptr(b1), ptr(W2), ptr(b2), ptr(mask), float(drop_p), float(max_depth),
+              B, Cb, Hd, nb, ptr(h1), ptr(widths), ptr(centers), _stream())
+
+
+def binpred_bwd(dcent, widths, h1, g, W1, W2, has_mask, drop_p, max_depth, dW2p, db2p, dW1p, db1p, dg):
+    B, Cb = g.shape
+    Hd, nb = W1.shape[0], W2.shape[0]
+    _dev(dcent, widths, h1, g, W1, W2, dW2p, db2p, dW1p, db1p, dg)
+    _lib.call('adn_binpred_bwd', ptr(dcent), ptr(widths), ptr(h1), ptr(g), ptr(W1), ptr(W2), int(bool(has_mask)),
+              float(drop_p), float(max_depth), B, Cb, Hd, nb, ptr(dW2p), ptr(db2p), ptr(dW1p), ptr(db1p), ptr(dg), _stream())
+
+
+def dropout_mask(mask, p, seed):
+    _dev(mask)
+    _lib.call('adn_dropout_mask', ptr(mask), mask.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, _stream())
+
+
+def bcast_add(gx, dg, scale, accumulate):
+    B, H, W, Cc = gx.shape
+    _dev(gx, dg)
+    _lib.call('adn_bcast_add', ptr(gx), ptr(dg), B, H * W, Cc, float(scale), int(bool(accumulate)), dtype_code(gx.dtype),
+              _stream())
+
+
+def bins_fwd(logits, centers, base):
+    B, H, W, nb = logits.shape
+    _dev(logits, centers, base)
+    _lib.call('adn_bins_fwd', ptr(logits), ptr(centers), B, H * W, nb, dtype_code(logits.dtype), ptr(base), _stream())
+
+
+def bins_bwd_workspace_bytes(B, HW, nb):
+    return _lib.load().adn_bins_bwd_workspace_bytes(B, HW, nb)
+
+
+def bins_bwd(logits, centers, base, dbase, dmean, dlogits, dcent, workspace):
+    B, H, W, nb = logits.shape
+    _dev(logits, centers, base, dbase, dmean, dlogits, dcent, workspace)
+    _lib.call('adn_bins_bwd', ptr(logits), ptr(centers), ptr(base), ptr(dbase), ptr(dmean), B, H * W, nb,
+              dtype_code(logits.dtype), ptr(dlogits), ptr(dcent), 0, ptr(workspace), _nbytes(workspace), _stream())
+
+
+def distill_pix_stats(base, resid, gt, teacher, max_depth, final_out, stats, workspace):
+    _dev(base, resid, gt, teacher, final_out, stats, workspace)
+    _lib.call('adn_distill_pix_stats', ptr(base), ptr(resid), ptr(gt), ptr(teacher), base.numel(), float(max_depth),
+              ptr(final_out), ptr(stats), ptr(workspace), _nbytes(workspace), _stream())
+
+
+def distill_pix_grad(base, resid, gt, teacher, max_depth, stats, lt, lr, ls, dbase, dres):
+    _dev(base, resid, gt, teacher, stats, dbase, dres)
+    _lib.call('adn_distill_pix_grad', ptr(base), ptr(resid), ptr(gt), ptr(teacher), base.numel(), float(max_depth),
+              ptr(stats), float(lt), float(lr), float(ls), ptr(dbase), ptr(dres), _stream())
+
+
+def featcos_grad(a, r, stats, coef, ga):
+    B, H, W, Cc = a.shape
+    _dev(a, r, stats, ga)
+    _lib.call('adn_featcos_grad', ptr(a), ptr(r), ptr(stats), B, H * W, Cc, dtype_code(a.dtype), float(coef), ptr(ga),
+              _stream())
+
+
+def distill_small(mean_s, mean_t, cent_s, cent_t, feat_stats, feat_channels, pix_stats, temperature, lambdas, terms,
+                  dmean, dcent):
+    """lambdas = (task, response, feature, bin, sparse); feat_stats: 5 tensors [B,3,C] or None (no teacher)."""
+    d = AdnDistillSmall()
+    has_t = mean_t is not None
+    _dev(mean_s, mean_t, cent_s, cent_t, pix_stats, terms, dmean, dcent)
+    d.mean_student, d.mean_teacher, d.centers_student, d.centers_teacher = ptr(mean_s), ptr(mean_t), ptr(cent_s), ptr(cent_t)
+    for i in range(5):
+        d.feat_stats[i] = ptr(feat_stats[i]) if has_t else None
+        d.feat_channels[i] = feat_channels[i] if has_t else 0
+    d.pix_stats = ptr(pix_stats)
+    d.B, d.nb, d.has_teacher = mean_s.shape[0], mean_s.shape[1], int(has_t)
+    d.temperature = float(temperature)
+    (d.lambda_task, d.lambda_response, d.lambda_feature, d.lambda_bin, d.lambda_sparse) = [float(v) for v in lambdas]
+    d.terms, d.dmean, d.dcent = ptr(terms), ptr(dmean), ptr(dcent)
+    _lib.call('adn_distill_small', C.byref(d), _stream())

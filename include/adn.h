@@ -167,7 +167,9 @@ int64_t adn_relu_bwd_stats_num_partials(int64_t pixels, int32_t C);
 int adn_relu_bwd_stats(void* g, const void* y, const void* z, const float* mean, const float* istd,
                        int64_t pixels, int32_t C, int32_t dtype, float* partials, void* stream);
 /* 1x1 conv to one channel + output activation (rgb_depth_model.py:195-209: outc, clamp(0, max_depth);
- * binaural_attention_model.py:330-337: sigmoid(outc) * max_depth, clamp).  act 0 clamp, 1 sigmoid.
+ * binaural_attention_model.py:330-337: sigmoid(outc) * max_depth, clamp).  act 0 clamp, 1 sigmoid,
+ * 2: tanh(z) * max_depth with no clamp (AdaBins residual head, adabins_distillation_model.py:330-335; pass
+ * max_depth = 0.05 * cfg max_depth).
  * zpre/out f32 [pixels]; backward writes gx (dtype [pixels][C]), dw [C], db [1]. */
 int adn_head1x1_fwd(const void* x, const float* w, const float* bias, int64_t pixels, int32_t C,
                     int32_t dtype, int32_t act, float max_depth, float* zpre, float* out, void* stream);
@@ -221,6 +223,71 @@ int adn_channel_sum(const void* x, int64_t rows, int32_t C, int32_t ld, int32_t 
 int adn_gate_bwd(void* t, const void* att, int64_t n, int32_t dtype, const float* gamma,
                  const float* gsum, const float* bias, int32_t C, float* dgamma, float* dbias,
                  float* dw, int64_t nw, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- AdaBins distillation model (adabins_distillation_model.py:105-207, 301-399) and DistillationLoss
+ * (utils_distillation_loss.py:48-238): everything that is not a convolution. ---- */
+/* Per-sample reductions over the HW rows of x [B][HW][ld] (first C columns):
+ *   nq = 1: out [B][C]    = scale * sum x        (AdaptiveAvgPool2d(1) :139, spatial mean of the bin logits :118-119)
+ *   nq = 3: out [B][3][C] = sum x^2, sum y^2, sum x*y   (cosine similarity of spatially normalised features :86-93) */
+int64_t adn_pool_workspace_bytes(int32_t B, int32_t HW, int32_t C, int32_t nq);
+int adn_pool(const void* x, const void* y, int32_t B, int32_t HW, int32_t C, int32_t ld, int32_t nq,
+             int32_t dtype, float scale, float* out, void* workspace, int64_t workspace_bytes, void* stream);
+/* AdaBinsBinPredictor (:127-149) on the pooled features g [B][Cb]: Linear(Cb,Hd) + ReLU + Dropout(mask, may be
+ * NULL) + Linear(Hd,nb) + Softmax -> widths; cumsum edges * max_depth -> centres (midpoints).  h1 = hidden
+ * activations after ReLU and dropout.  Backward takes d loss / d centres and writes PER-SAMPLE partial weight
+ * gradients dW2p [B][nb][Hd], db2p [B][nb], dW1p [B][Hd][Cb], db1p [B][Hd] (sum over B with adn_channel_sum) and
+ * dg [B][Cb]. */
+int adn_binpred_fwd(const float* g, const float* W1, const float* b1, const float* W2, const float* b2,
+                    const uint8_t* mask, float drop_p, float max_depth, int32_t B, int32_t Cb,
+                    int32_t Hd, int32_t nb, float* h1, float* widths, float* centers, void* stream);
+int adn_binpred_bwd(const float* dcent, const float* widths, const float* h1, const float* g,
+                    const float* W1, const float* W2, int32_t has_mask, float drop_p, float max_depth,
+                    int32_t B, int32_t Cb, int32_t Hd, int32_t nb, float* dW2p, float* db2p, float* dW1p,
+                    float* db1p, float* dg, void* stream);
+/* Bernoulli(1-p) keep mask from a counter-based hash of (seed, index): nn.Dropout(0.1) :144 (statistically
+ * equivalent draw; torch's RNG stream is not reproducible from outside torch). */
+int adn_dropout_mask(uint8_t* mask, int64_t n, float p, uint64_t seed, void* stream);
+/* gx [B][HW][C] (+)= scale * dg [B][C]: backward of the average pool. */
+int adn_bcast_add(void* gx, const float* dg, int32_t B, int32_t HW, int32_t C, float scale,
+                  int32_t accumulate, int32_t dtype, void* stream);
+/* Soft binning (:198-201): base[pix] = sum_k softmax(logits[pix])_k * centres[b][k].  Backward:
+ * dlogits = p_k (c_k - base) dbase + dmean[b][k] / HW (dmean: gradient wrt the spatial mean of the logits, may be
+ * NULL), dcent [B][nb] = sum_pix p_k dbase. */
+int adn_bins_fwd(const void* logits, const float* centers, int32_t B, int32_t HW, int32_t nb,
+                 int32_t dtype, float* base, void* stream);
+int64_t adn_bins_bwd_workspace_bytes(int32_t B, int32_t HW, int32_t nb);
+int adn_bins_bwd(const void* logits, const float* centers, const float* base, const float* dbase,
+                 const float* dmean, int32_t B, int32_t HW, int32_t nb, int32_t dtype, void* dlogits,
+                 float* dcent, int32_t dcent_accumulate, void* workspace, int64_t workspace_bytes,
+                 void* stream);
+/* Pixel terms of DistillationLoss with valid = gt > 0 (train_adabins_distillation.py:449):
+ * final = clamp(base + resid, 0, max_depth) (:337); stats f64[4] = [N_valid, sum|final-gt|, sum(final-teacher)^2,
+ * sum|resid|] (teacher may be NULL); gradients wrt base and resid for
+ * lambda_task * L1 + lambda_response * MSE + lambda_sparse * mean|resid|.  workspace: 32 KiB. */
+int adn_distill_pix_stats(const float* base, const float* resid, const float* gt, const float* teacher,
+                          int64_t n, float max_depth, float* final_out, double* stats, void* workspace,
+                          int64_t workspace_bytes, void* stream);
+int adn_distill_pix_grad(const float* base, const float* resid, const float* gt, const float* teacher,
+                         int64_t n, float max_depth, const double* stats, float lambda_task,
+                         float lambda_response, float lambda_sparse, float* dbase, float* dres,
+                         void* stream);
+/* ga += coef * d cos(a, r) / d a per (sample, channel) over the spatial positions, stats from adn_pool(nq=3). */
+int adn_featcos_grad(const void* a, const void* r, const float* stats, int32_t B, int32_t HW, int32_t C,
+                     int32_t dtype, float coef, void* ga, void* stream);
+/* The small terms and the total (utils_distillation_loss.py:105-143, 220-226): feature loss from the five
+ * statistics, KL(batchmean) of the temperature-softened mean logits, bin-centre MSE; terms f32[8] = task, response,
+ * feature, bin, bin_centers, sparse, total, N_valid; dmean / dcent [B][nb] = gradients wrt the student's mean logits /
+ * the extra gradient wrt its bin centres. */
+typedef struct {
+  const float* mean_student; const float* mean_teacher;        /* [B][nb] */
+  const float* centers_student; const float* centers_teacher;  /* [B][nb] */
+  const float* feat_stats[5]; int32_t feat_channels[5];        /* [B][3][C] per level x1..x5 */
+  const double* pix_stats;
+  int32_t B, nb, has_teacher;
+  float temperature, lambda_task, lambda_response, lambda_feature, lambda_bin, lambda_sparse;
+  float* terms; float* dmean; float* dcent;
+} AdnDistillSmall;
+int adn_distill_small(const AdnDistillSmall* d, void* stream);
 
 /* NCHW f32 <-> NHWC dtype layout conversion of the network input/output
  * (model(audio) boundary, train.py:642).  dst has c_pad >= C channels, the extra ones zero. */

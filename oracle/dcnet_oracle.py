@@ -165,3 +165,80 @@ def depth_loss(pred, target, lambda_l1=1.0, lambda_smooth=0.1):
     dx = (pred[:, :, :, :-1] - pred[:, :, :, 1:]).abs()
     dy = (pred[:, :, :-1, :] - pred[:, :, 1:, :]).abs()
     return lambda_l1 * l1 + lambda_smooth * (dx.mean() + dy.mean())
+
+
+# ---- AdaBins distillation model (adabins_distillation_model.py) ----------------------------------------------
+def bin_predictor(sd, prefix, x5, max_depth, drop_mask=None, drop_p=0.1):
+    """AdaBinsBinPredictor.forward (:127-149): avgpool -> Linear -> ReLU -> Dropout -> Linear -> Softmax -> cumsum
+    edges * max_depth -> midpoints.  ``drop_mask`` (0/1, [B,256]) replaces the train-mode Dropout draw."""
+    g = x5.mean((2, 3))
+    h = F.relu(F.linear(g, sd[prefix + '.predictor.0.weight'], sd[prefix + '.predictor.0.bias']))
+    if drop_mask is not None:
+        h = h * drop_mask / (1.0 - drop_p)
+    widths = torch.softmax(F.linear(h, sd[prefix + '.predictor.3.weight'], sd[prefix + '.predictor.3.bias']), 1)
+    edges = torch.cat([torch.zeros_like(widths[:, :1]), torch.cumsum(widths, 1)], 1) * max_depth
+    return (edges[:, :-1] + edges[:, 1:]) / 2, widths
+
+
+def adabins_branch(sd, enc, pred, dec, x, max_depth, training, new_stats, drop_mask=None):
+    """forward_audio / forward_rgb (:301-399).  The reference runs the decoder twice on identical inputs (once inside
+    the decoder module, once for the residual head); the second pass reproduces the first one's activations, so
+    it is evaluated once here and only its side effect -- a second BatchNorm running-stat update in train mode -- is
+    replayed (``new_stats`` holds the twice-updated statistics)."""
+    feats = encoder(sd, enc + '.', _q(x), training, new_stats)
+    centers, widths = bin_predictor(sd, pred, feats[4], max_depth, drop_mask)
+    dstats = {}
+    d, skip = feats[4], [feats[3], feats[2], feats[1], feats[0]]
+    for i in range(4):
+        d = up(sd, f'{dec}.up{i + 1}', d, skip[i], training, dstats)
+    if training:
+        for k, v in dstats.items():                     # second update with the same batch statistic
+            once = v
+            prev = sd[k]
+            batch = (once - (1 - BN_MOMENTUM) * prev) / BN_MOMENTUM
+            new_stats[k] = (1 - BN_MOMENTUM) * once + BN_MOMENTUM * batch
+    logits = F.conv2d(d, sd[dec + '.class_head.weight'], sd[dec + '.class_head.bias'])
+    probs = torch.softmax(logits, 1)
+    base = (probs * centers[:, :, None, None]).sum(1, keepdim=True)
+    residual = torch.tanh(F.conv2d(d, sd['residual_head.weight'], sd['residual_head.bias'])) * (max_depth * 0.05)
+    final = torch.clamp(base + residual, 0, max_depth)
+    return {'features': {f'x{i + 1}': feats[i] for i in range(5)}, 'bin_centers': centers, 'bin_widths': widths,
+            'bin_logits': logits, 'base_depth': base, 'residual': residual, 'final_depth': final}
+
+
+def adabins_forward(sd, audio, rgb=None, max_depth=30.0, training=True, drop_mask_audio=None, drop_mask_rgb=None):
+    """AdaBinsDistillationModel.forward (:401-426) for output_size == input size; teacher under no_grad."""
+    new_stats = {}
+    a = adabins_branch(sd, 'audio_encoder', 'audio_bin_predictor', 'audio_decoder', audio, max_depth, training,
+                       new_stats, drop_mask_audio)
+    r = None
+    if rgb is not None:
+        with torch.no_grad():
+            r = adabins_branch(sd, 'rgb_encoder', 'rgb_bin_predictor', 'rgb_decoder', rgb, max_depth, training,
+                               new_stats, drop_mask_rgb)
+    return {'audio': a, 'rgb': r}, new_stats
+
+
+def distillation_loss(output, gt, valid, lambda_task=2.0, lambda_response=0.3, lambda_feature=0.2, lambda_bin=0.05,
+                      lambda_sparse=0.1, temperature=4.0):
+    """DistillationLoss.forward (utils_distillation_loss.py:147-238).  Returns (total, dict of terms)."""
+    a, r = output['audio'], output['rgb']
+    task = (a['final_depth'][valid] - gt[valid]).abs().mean()
+    zero = torch.zeros((), dtype=gt.dtype)
+    resp = feat = kl = cm = zero
+    if r is not None:
+        resp = ((a['final_depth'][valid] - r['final_depth'][valid].detach()) ** 2).mean()
+        tot = 0.0
+        for lv in ('x1', 'x2', 'x3', 'x4', 'x5'):
+            af = F.normalize(a['features'][lv].flatten(2), dim=2)
+            rf = F.normalize(r['features'][lv].detach().flatten(2), dim=2)
+            tot = tot + (1 - (af * rf).sum(2).mean())
+        feat = tot / 5
+        al = F.log_softmax(a['bin_logits'].mean((2, 3)) / temperature, 1)
+        rl = torch.softmax(r['bin_logits'].detach().mean((2, 3)) / temperature, 1)
+        kl = F.kl_div(al, rl, reduction='batchmean')
+        cm = ((a['bin_centers'] - r['bin_centers'].detach()) ** 2).mean()
+    sparse = a['residual'][valid].abs().mean()
+    total = (lambda_task * task + lambda_response * resp + lambda_feature * feat + lambda_bin * (kl + cm) +
+             lambda_sparse * sparse)
+    return total, {'task': task, 'response': resp, 'feature': feat, 'bin': kl, 'bin_centers': cm, 'sparse': sparse}

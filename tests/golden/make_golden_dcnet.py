@@ -144,7 +144,96 @@ def binaural_case(name='binaural64_bc8', bc=8, S=64, B=2, lr=1e-3, wd=0.01, max_
     save(name, out)
 
 
+
+
+def perturb_biases(model, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():                       # non-trivial biases (the init sets all conv biases to 0)
+        for m in model.modules():
+            if isinstance(m, (torch.nn.Linear, torch.nn.Conv2d)) and m.bias is not None:
+                m.bias.copy_(0.2 * torch.randn(m.bias.shape, generator=g))
+
+
+def sample(t, n=512):
+    """Deterministic strided sample of a tensor (whole tensor when small)."""
+    f = t.detach().reshape(-1)
+    if f.numel() <= n:
+        return f.clone().numpy()
+    idx = torch.linspace(0, f.numel() - 1, n).long()
+    return f[idx].clone().numpy()
+
+
+def adabins_case(name='adabins32_bc64', bc=64, nb=128, S=32, B=2, lr=2e-3, max_depth=30.0):
+    """models/adabins_distillation_model.py:462 create_adabins_distillation_model, utils_distillation_loss.py:20
+    DistillationLoss with the trainer's default weights (train_adabins_distillation.py:179-188), one step of
+    train_adabins_distillation.py:445-456 (mode='train' with the RGB teacher, gt>0 mask, clip_grad_norm_(1.0),
+    AdamW).  The reference decoder hard-codes its channel counts (Up(1024,..), Up(768,..), :186-189), so the model
+    only exists at base_channels=64 (42.6 M parameters): the fixture holds inputs, outputs, the loss terms and, per
+    parameter, the gradient norm plus a strided 512-element sample of the gradient and of the updated value; the
+    initial weights are regenerated from the seed (same-seed-same-weights) and the perturbations below.
+    Dropout(0.1) of the bin predictors is set to p=0: its draw comes from torch's global RNG stream and cannot
+    be reproduced by another implementation."""
+    from models.adabins_distillation_model import create_adabins_distillation_model
+    from utils_distillation_loss import DistillationLoss
+    torch.manual_seed(0)
+    model = create_adabins_distillation_model(n_bins=nb, base_channels=bc, output_size=S, max_depth=max_depth)
+    perturb_bn(model, 3)
+    perturb_biases(model, 9)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    out = {}
+    for k, v in model.state_dict().items():
+        out['sd0s/' + k] = sample(v) if v.is_floating_point() else v.clone().numpy()
+    g = torch.Generator().manual_seed(1234)
+    audio = torch.rand(B, 2, S, S, generator=g)
+    rgb = torch.rand(B, 3, S, S, generator=g)
+    gt = max_depth * torch.rand(B, 1, S, S, generator=g)
+    gt[gt < 0.1 * max_depth] = 0.0
+    out['audio'], out['rgb'], out['gt'] = audio.numpy(), rgb.numpy(), gt.numpy()
+    model.eval()
+    with torch.no_grad():
+        o = model(audio, rgb=None, mode='inference')
+        out['eval/final_depth'] = o['audio']['final_depth'].numpy()
+        out['eval/bin_centers'] = o['audio']['bin_centers'].numpy()
+    model.train()
+    crit = DistillationLoss(lambda_task=1.0, lambda_response=0.5, lambda_feature=0.3, lambda_bin=0.2,
+                            lambda_sparse=0.1, temperature=4.0)
+    opt = torch.optim.AdamW(filter(lambda p: p.requires_grad, model.parameters()), lr=lr)
+    o = model(audio, rgb=rgb, mode='train')
+    for side in ('audio', 'rgb'):
+        for k in ('bin_centers', 'bin_widths', 'base_depth', 'residual', 'final_depth'):
+            out[f'train/{side}/{k}'] = o[side][k].detach().numpy()
+        out[f'train/{side}/logits_mean'] = o[side]['bin_logits'].detach().mean((2, 3)).numpy()
+        out[f'train/{side}/x5'] = o[side]['features']['x5'].detach().numpy()
+    valid = gt > 0
+    loss, parts = crit(o, gt, valid)
+    opt.zero_grad()
+    loss.backward()
+    out['loss'] = np.float64(loss.item())
+    out['loss_parts'] = np.array([parts[k] for k in ('task', 'response', 'feature', 'bin', 'bin_centers', 'sparse')],
+                                 dtype=np.float64)
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            out['gnorm/' + k] = np.float64(p.grad.double().norm().item())
+            out['gs/' + k] = sample(p.grad)
+    tn = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
+    out['grad_norm'] = np.float64(tn.item())
+    opt.step()
+    for k, v in model.state_dict().items():
+        out['sd1s/' + k] = sample(v) if v.is_floating_point() else v.clone().numpy()
+    out['meta'] = np.array([bc, nb, S, B], dtype=np.int64)
+    out['hyper'] = np.array([lr, max_depth, 1.0, 0.5, 0.3, 0.2, 0.1, 4.0], dtype=np.float64)
+    save(name, out)
+
+
 if __name__ == '__main__':
+    import sys as _sys
     torch.set_num_threads(8)
-    rgb_case()
-    binaural_case()
+    which = _sys.argv[1:] or ['rgb', 'binaural', 'adabins']
+    if 'rgb' in which:
+        rgb_case()
+    if 'binaural' in which:
+        binaural_case()
+    if 'adabins' in which:
+        adabins_case()
