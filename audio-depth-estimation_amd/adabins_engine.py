@@ -346,6 +346,18 @@ class AdaBinsTrainer:
         self.clip_norm = clip_norm
         self._ready = False
 
+    @classmethod
+    def from_criterion(cls, engine, criterion, **kw):
+        """Build from a utils_distillation_loss.DistillationLoss / AdaptiveDistillationLoss instance."""
+        t = cls(engine, **kw)
+        t.set_criterion(criterion)
+        return t
+
+    def set_criterion(self, criterion):
+        """Take the loss weights / temperature of ``criterion`` (call again after AdaptiveDistillationLoss.set_epoch)."""
+        c = criterion.criterion() if hasattr(criterion, 'get_adaptive_weights') else criterion
+        self.lambdas, self.temperature = c.weights(), c.temperature
+
     def _setup(self, dev):
         eng = self.engine
         f64 = dict(dtype=torch.float64, device=dev)

@@ -234,3 +234,37 @@ def test_adabins_golden_reference_parity_f32():
             np.testing.assert_array_equal(_sample(v.cpu()), ref, err_msg=k)       # the teacher is not touched
         else:
             assert float(np.abs(_sample(v.cpu()) - ref).max()) <= 2.02 * lr, k   # within one AdamW step everywhere
+
+
+def test_distillation_loss_module_and_adaptive_schedule():
+    """utils_distillation_loss mirror: forward values from a model output dict vs the reference's loss terms; the
+    adaptive weight schedule vs the reference formulas (utils_distillation_loss.py:268-304)."""
+    from audio_depth_estimation_amd.utils_distillation_loss import AdaptiveDistillationLoss, DistillationLoss
+    from audio_depth_estimation_amd.adabins_engine import AdaBinsTrainer
+    z = np.load(os.path.join(GOLDEN, 'adabins32_bc64.npz'))
+    lr, max_depth, lt, lr_, lf, lb, ls, temp = [float(v) for v in z['hyper']]
+    model = adabins_initial_state(z)
+    model.compute_dtype = torch.float32
+    model = model.to(DEV).train()
+    audio, rgb, gt = [torch.from_numpy(z[k]).to(DEV) for k in ('audio', 'rgb', 'gt')]
+    out = model(audio, rgb=rgb, mode='train')
+    assert set(out['audio'].keys()) == {'features', 'bin_centers', 'bin_widths', 'bin_logits', 'base_depth', 'residual',
+                                        'final_depth'}
+    assert out['audio']['bin_logits'].shape == (2, 128, 32, 32) and out['audio']['features']['x5'].shape == (2, 512, 2, 2)
+    assert rel_err(out['audio']['features']['x5'], z['train/audio/x5']) <= 2e-4
+    assert rel_err(out['rgb']['features']['x5'], z['train/rgb/x5']) <= 2e-4
+    crit = DistillationLoss(lt, lr_, lf, lb, ls, temp)
+    total, parts = crit(out, gt, gt > 0)
+    got = np.array([parts[k] for k in ('task', 'response', 'feature', 'bin', 'bin_centers', 'sparse')])
+    np.testing.assert_allclose(got, z['loss_parts'], rtol=2e-4, atol=1e-6)
+    assert abs(float(total) - float(z['loss'])) <= 2e-4 * abs(float(z['loss']))
+    ad = AdaptiveDistillationLoss(max_epochs=200)
+    for epoch, want in ((0, (2.0, 0.1, 0.05, 0.05)), (100, (2.5, 0.1 + 0.4 * 0.4 / 0.9, 0.3, 0.035)),
+                        (200, (3.0, 0.5, 0.2, 0.02))):
+        ad.set_epoch(epoch)
+        w = ad.get_adaptive_weights()
+        np.testing.assert_allclose([w['task'], w['response'], w['feature'], w['bin']], want, rtol=1e-6)
+    tr = AdaBinsTrainer.from_criterion(model.engine(), ad, lr=1e-4)
+    assert tr.lambdas[0] == 3.0 and tr.temperature == 4.0
+    with pytest.raises(RuntimeError):
+        model(audio.cpu(), rgb=None, mode='inference')
