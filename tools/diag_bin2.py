@@ -32,4 +32,4 @@ for dtype in (torch.bfloat16,):
     for k, prm in model.named_parameters():
         got = eng.grad_view(prm).detach().float().cpu().reshape(-1); ref = sd64[k].grad.reshape(-1).float()
         cos = float(torch.dot(got, ref) / (got.norm() * ref.norm() + 1e-30))
-        print(f'{k:55s} cos {cos:.4f}')
+        print(f'{k:55s} cos {cos:.4f}' + (f'  got {float(got[0]):.4e} ref {float(ref[0]):.4e}' if got.numel() == 1 else ''))
