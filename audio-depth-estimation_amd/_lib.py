@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libadn.so')
+LIB_PATH = os.environ.get('ADN_LIB', os.path.join(_HERE, 'libadn.so'))      # ADN_LIB: A/B builds (tools/ab)
 
 ADN_F32, ADN_BF16 = 0, 1
 GEMM_S2, GEMM_T2, GEMM_S1 = 0, 1, 2

@@ -1,4 +1,6 @@
-// Weight-gradient kernel of the k4/s2/p1 Conv2d / ConvTranspose2d pair (gfx950).
+// Weight-gradient kernel of the k4/s2/p1 Conv2d / ConvTranspose2d pair (gfx950) -- the U-Net baseline's layers.
+// (The stride-1 3x3 / 1x1 geometry of the DoubleConv nets lives in wgrad.hip: same structure with run-time tap
+// geometry; keeping this k4 instantiation separate keeps its constant-folded addressing, measured 5-10 % faster.)
 //
 //   dW[r][tap][c] = sum_{m on the small grid} plain[m][r] * gath[b, 2i-1+ky, 2j-1+kx][c]
 //
@@ -22,17 +24,15 @@ struct WParams {
   int tiles_r, tiles_c;
   float* out;     // dW or slab base
   int64_t out_elems;
-  int c_valid;    // gathered channels actually stored (compact [R][taps][c_valid]); == C0+C1 normally
-  int geom;       // 0: k4 s2 gather (16 taps, gathered tensor on the 2x grid); ADN_GEMM_S1: ks x ks, same grid
-  int ks;
+  int c_valid;    // gathered channels actually stored (compact [R][16][c_valid]); == C0+C1 normally
 };
 
 // 128 zero bytes: LDS-DMA source for rows beyond M / padded taps / the upper half of an R=64 tile
-__device__ u32x4_t adn_wg_zero_page[8];
+__device__ u32x4_t adn_wg4_zero_page[8];
 
 __device__ __forceinline__ int swz_f(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
-template <typename T, bool FAST, bool MIXED, bool S1>
+template <typename T, bool FAST>
 __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins exist only in the device pass
   constexpr int EPC = 16 / (int)sizeof(T);
@@ -58,12 +58,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
   const int tile_c = lid % p.tiles_c;
   const int tile_r = (lid / p.tiles_c) % p.tiles_r;
   const int split = lid / ntile;
-  const int Hs = p.Hs, Ws = p.Ws;
-  constexpr bool s1 = S1;                                       // compile-time geometry: the k4 path keeps its constants
-  const int Hl = s1 ? Hs : 2 * Hs, Wl = s1 ? Ws : 2 * Ws;      // grid of the gathered tensor
-  const int kside = s1 ? p.ks : 4, kpad = s1 ? (p.ks >> 1) : 1, gstr = s1 ? 1 : 2;
-  const int ntap = kside * kside;
-  const bool has_pad = !s1 || p.ks == 3;
+  const int Hs = p.Hs, Ws = p.Ws, Hl = 2 * Hs, Wl = 2 * Ws;
   const int C = p.C0 + p.C1;
 
   // LDS-DMA staging (global_load_lds_dwordx4): wave w writes 1 KiB = RPP/4 consecutive tile rows per pass,
@@ -74,13 +69,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
   const int pc = tid % CPRW;
   const int prow0 = tid / CPRW;
   constexpr int NV = sizeof(T) == 2 ? 1 : 2;
-  const T* zero = reinterpret_cast<const T*>(adn_wg_zero_page);
+  const T* zero = reinterpret_cast<const T*>(adn_wg4_zero_page);
   const T* psrc[NV];
   int Rsrc[NV];
   bool r_ok[NV];
   const T* gsrc[NV];
   int Csrc[NV], ky[NV], kx[NV];
-  bool col_ok[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     const int row = prow0 + RPP * v;
@@ -97,9 +91,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
     const int gcol = tile_c * 128 + lc * EPC;
     const int tap = gcol / C;
     const int cch = gcol - tap * C;
-    col_ok[v] = S1 ? (tap < ntap) : true;   // S1: the last column tile may be partial (9*C is not a multiple of 128)
-    ky[v] = tap / kside;
-    kx[v] = tap - ky[v] * kside;
+    ky[v] = tap >> 2;
+    kx[v] = tap & 3;
     if (cch < p.C0) {
       gsrc[v] = reinterpret_cast<const T*>(p.gath0) + cch;
       Csrc[v] = p.C0;
@@ -124,26 +117,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
   constexpr int ESZ = (int)sizeof(T);
   unsigned pvoff[PASSES], gvoff[PASSES];
   bool m_y0[PASSES], m_y1[PASSES], m_x0[PASSES], m_x1[PASSES], m_c[PASSES];
-  __amdgpu_buffer_rsrc_t rsp, rsg, rsg1;
-  bool lsec[PASSES];
-  constexpr bool mixed = MIXED;
+  __amdgpu_buffer_rsrc_t rsp, rsg;
   int Rs_u = 0, Cs_u = 0, lgWs = 0;
   if constexpr (FAST) {
     lgWs = 31 - __builtin_clz((unsigned)Ws);
     const bool psecond = tile_r * 128 >= p.R0;
     Rs_u = psecond ? p.R1 : p.R0;
     const char* pb = reinterpret_cast<const char*>(psecond ? p.plain1 : p.plain0);
-    // a 128-column tile normally lies inside one gathered source; when it does not (C0 = C1 = 64, or several
-    // taps of a narrow two-source concat per tile) the source is a per-lane constant and the two descriptors
-    // are selected by an exec-masked branch
-    const bool gsecond = !mixed && (C >= 128) && ((tile_c * 128) % C) >= p.C0;
+    const bool gsecond = (C >= 128) && ((tile_c * 128) % C) >= p.C0;
     Cs_u = gsecond ? p.C1 : p.C0;
-    const char* gb = reinterpret_cast<const char*>(gsecond ? p.gath1 : p.gath0) - (int64_t)kpad * (Wl + 1) * Cs_u * ESZ;
+    const char* gb = reinterpret_cast<const char*>(gsecond ? p.gath1 : p.gath0) - (int64_t)(Wl + 1) * Cs_u * ESZ;
     rsp = __builtin_amdgcn_make_buffer_rsrc((void*)pb, 0, 0x7ffffff0, 0x00020000);
     rsg = __builtin_amdgcn_make_buffer_rsrc((void*)gb, 0, 0x7ffffff0, 0x00020000);
-    rsg1 = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(reinterpret_cast<const char*>(p.C1 ? p.gath1 : p.gath0) - (int64_t)kpad * (Wl + 1) * p.C1 * ESZ), 0,
-        0x7ffffff0, 0x00020000);
     const bool rows_in_line = Ws >= BKP;          // a step stays inside one image row
     const int q = rows_in_line ? 1 : BKP / Ws;    // image rows per step otherwise
 #pragma unroll
@@ -157,26 +142,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
       pvoff[k] = r_ok[v] ? (unsigned)((r * Rs_u + roff) * ESZ) : OOB;
       const int gcol = tile_c * 128 + lc * EPC;
       const int tap = gcol / C;
-      int cch = gcol - tap * C - (gsecond ? p.C0 : 0);
-      int Cs_l = Cs_u;
-      lsec[k] = false;
-      if (mixed && cch >= p.C0) {
-        lsec[k] = true;
-        cch -= p.C0;
-        Cs_l = p.C1;
-      }
+      const int cch = gcol - tap * C - (gsecond ? p.C0 : 0);
       const int jx = r & (Ws - 1);
-      // linear index of the gathered pixel at tap (kpad,kpad): s2: 4m - 2j, s1: m  (scalar part + lane part)
-      const int L = s1 ? r : (rows_in_line ? 2 * r : 4 * r - 2 * jx);
-      gvoff[k] = (unsigned)(((L + ky[v] * Wl + kx[v]) * Cs_l + cch) * ESZ);
+      const int L = rows_in_line ? 2 * r : 4 * r - 2 * jx;
+      gvoff[k] = (unsigned)(((L + ky[v] * Wl + kx[v]) * Cs_u + cch) * ESZ);
       const int a = r >> lgWs;                    // image row inside the step (0 when rows_in_line)
-      const int klast = kside - 1;
-      m_y0[k] = has_pad && (ky[v] == 0) && (rows_in_line || a == 0);
-      m_y1[k] = has_pad && (ky[v] == klast) && (rows_in_line || a == q - 1);
-      m_x0[k] = has_pad && rows_in_line && (kx[v] == 0) && (r == 0);
-      m_x1[k] = has_pad && rows_in_line && (kx[v] == klast) && (r == BKP - 1);
-      m_c[k] = !col_ok[v] ||
-               (has_pad && !rows_in_line && (((kx[v] == 0) && jx == 0) || ((kx[v] == klast) && jx == Ws - 1)));
+      m_y0[k] = (ky[v] == 0) && (rows_in_line || a == 0);
+      m_y1[k] = (ky[v] == 3) && (rows_in_line || a == q - 1);
+      m_x0[k] = rows_in_line && (kx[v] == 0) && (r == 0);
+      m_x1[k] = rows_in_line && (kx[v] == 3) && (r == BKP - 1);
+      m_c[k] = !rows_in_line && (((kx[v] == 0) && jx == 0) || ((kx[v] == 3) && jx == Ws - 1));
     }
   }
 
@@ -192,21 +167,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
       const bool top = si == 0, bot = si == Hs - q;
       const bool left = rows_in_line && sj == 0, right = rows_in_line && sj == Ws - BKP;
       const int psoff = m0 * Rs_u * ESZ;
-      const int gpix = s1 ? m0 : 4 * m0 - 2 * sj;
-      const int gsoff = gpix * Cs_u * ESZ;
-      const int gsoff1 = gpix * p.C1 * ESZ;
+      const int gsoff = (4 * m0 - 2 * sj) * Cs_u * ESZ;
 #pragma unroll
       for (int k = 0; k < PASSES; ++k) {
         const bool inval = m_c[k] || (top && m_y0[k]) || (bot && m_y1[k]) || (left && m_x0[k]) || (right && m_x1[k]);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsp, (lptr_t)(pdst + k * (RPP * ROWB)), 16, pvoff[k], psoff, 0, 0);
-        const unsigned gv = inval ? OOB : gvoff[k];
-        if constexpr (MIXED) {
-          // LDS-DMA lands at M0 base + lane * 16 for ACTIVE lanes only, so the two masked halves compose
-          if (lsec[k]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsg1, (lptr_t)(gdst + k * (RPP * ROWB)), 16, gv, gsoff1, 0, 0);
-          else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsg, (lptr_t)(gdst + k * (RPP * ROWB)), 16, gv, gsoff, 0, 0);
-        } else {
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsg, (lptr_t)(gdst + k * (RPP * ROWB)), 16, gv, gsoff, 0, 0);
-        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsg, (lptr_t)(gdst + k * (RPP * ROWB)), 16,
+                                                 inval ? OOB : gvoff[k], gsoff, 0, 0);
       }
     } else {
 #pragma unroll
@@ -221,8 +188,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
           const int rem = m - b * (Hs * Ws);
           const int i = rem / Ws;
           const int j = rem - i * Ws;
-          const int iy = gstr * i - kpad + ky[v], ix = gstr * j - kpad + kx[v];
-          if (col_ok[v] && (unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl)
+          const int iy = 2 * i - 1 + ky[v], ix = 2 * j - 1 + kx[v];
+          if ((unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl)
             gg = gsrc[v] + (((int64_t)b * Hl + iy) * Wl + ix) * Csrc[v];
         }
         __builtin_amdgcn_global_load_lds((gptr_t)pp, (lptr_t)(pdst + k * (RPP * ROWB)), 16, 0, 0);
@@ -322,12 +289,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
   const int r0 = tid >> 5;    // 8 rows per pass
   const int R = p.R0 + p.R1;
   if (p.c_valid == C) {
-    const int64_t ldo = (int64_t)ntap * C;
-    const bool cok = S1 ? (tile_c * 128 + cq * 4 < ntap * C) : true;
+    const int64_t ldo = (int64_t)16 * C;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       const int row = r0 + 8 * k;
-      if (cok && tile_r * 128 + row < R) {
+      if (tile_r * 128 + row < R) {
         const f32x4_t v = *reinterpret_cast<const f32x4_t*>(ct + row * LDC + cq * 4);
         *reinterpret_cast<f32x4_t*>(out + (int64_t)(tile_r * 128 + row) * ldo + tile_c * 128 + cq * 4) = v;
       }
@@ -340,8 +306,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
       for (int e = 0; e < 4; ++e) {
         const int gc = tile_c * 128 + cq * 4 + e;
         const int tp = gc / C, cc = gc - tp * C;
-        if (tp < ntap && cc < p.c_valid)
-          out[((int64_t)(tile_r * 128 + row) * ntap + tp) * p.c_valid + cc] = ct[row * LDC + cq * 4 + e];
+        if (cc < p.c_valid)
+          out[((int64_t)(tile_r * 128 + row) * 16 + tp) * p.c_valid + cc] = ct[row * LDC + cq * 4 + e];
       }
     }
   }
@@ -351,19 +317,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
 // generic path: one thread per (output element, split)
 template <typename T>
 __global__ __launch_bounds__(256) void wgrad_direct_kernel(WParams p, int pix_per_split) {
-  const int Hs = p.Hs, Ws = p.Ws;
-  const bool s1 = p.geom == ADN_GEMM_S1;
-  const int Hl = s1 ? Hs : 2 * Hs, Wl = s1 ? Ws : 2 * Ws;
-  const int kside = s1 ? p.ks : 4, kpad = s1 ? (p.ks >> 1) : 1, gstr = s1 ? 1 : 2;
-  const int ntap = kside * kside;
+  const int Hs = p.Hs, Ws = p.Ws, Hl = 2 * Hs, Wl = 2 * Ws;
+  const int C = p.C0 + p.C1;
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= p.out_elems) return;
   const int split = blockIdx.y;
   const int cv = p.c_valid;
   const int c = (int)(e % cv);
-  const int tap = (int)((e / cv) % ntap);
-  const int r = (int)(e / ((int64_t)ntap * cv));
-  const int ky = tap / kside, kx = tap - ky * kside;
+  const int tap = (int)((e / cv) % 16);
+  const int r = (int)(e / ((int64_t)16 * cv));
+  (void)C;
+  const int ky = tap >> 2, kx = tap & 3;
   const T* ps = r < p.R0 ? reinterpret_cast<const T*>(p.plain0) + r : reinterpret_cast<const T*>(p.plain1) + (r - p.R0);
   const int Rs = r < p.R0 ? p.R0 : p.R1;
   const T* gs = c < p.C0 ? reinterpret_cast<const T*>(p.gath0) + c : reinterpret_cast<const T*>(p.gath1) + (c - p.C0);
@@ -376,7 +340,7 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(WParams p, int pix_pe
     const int b = m / (Hs * Ws);
     const int rem = m - b * (Hs * Ws);
     const int i = rem / Ws, j = rem - i * Ws;
-    const int iy = gstr * i - kpad + ky, ix = gstr * j - kpad + kx;
+    const int iy = 2 * i - 1 + ky, ix = 2 * j - 1 + kx;
     if ((unsigned)iy >= (unsigned)Hl || (unsigned)ix >= (unsigned)Wl) continue;
     const int64_t pix = ((int64_t)b * Hl + iy) * Wl + ix;
     acc += ElemTraits<T>::load(ps + (int64_t)m * Rs) * ElemTraits<T>::load(gs + pix * Cs);
@@ -411,7 +375,6 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* slab, float*
 struct WPlan {
   bool mfma;
   bool fast;
-  bool mixed;    // fast path whose 128-column tiles straddle the two gathered sources
   int nsplit, steps, tiles_r, tiles_c, pix_per_split;
   int64_t out_elems, slab_bytes;
 };
@@ -420,26 +383,23 @@ void make_wplan(const AdnWgradDesc* d, WPlan* pl) {
   const int R = d->R0 + d->R1, C = d->C0 + d->C1;
   const int64_t msmall = (int64_t)d->B * d->Hs * d->Ws;
   const int cv = d->c_valid > 0 ? d->c_valid : C;
-  const int ntap = d->geom == ADN_GEMM_S1 ? d->ks * d->ks : 16;
-  pl->out_elems = (int64_t)R * ntap * cv;
+  pl->out_elems = (int64_t)R * 16 * cv;
   const int epc = d->dtype == ADN_BF16 ? 8 : 4;
   // sources are selected per 16-byte chunk, so a tile may straddle the two plain / gathered sources
-  const bool aligned = (R % 64 == 0) && (d->R0 % epc == 0) && (C % epc == 0) && (d->C0 % epc == 0) &&
-                       (C >= 128 ? (C % 128 == 0) : (128 % C == 0));
+  const bool aligned = (R % 64 == 0) && (d->R0 % epc == 0) && ((16 * C) % 128 == 0) && (C % epc == 0) &&
+                       (d->C0 % epc == 0) && (C >= 128 ? (C % 128 == 0) : (128 % C == 0));
   pl->mfma = aligned;
   pl->fast = false;
-  pl->mixed = false;
   if (aligned) {
     const int bkp = d->dtype == ADN_BF16 ? 64 : 32;
-    const int64_t esz = d->dtype == ADN_BF16 ? 2 : 4;
     auto pow2 = [](int x) { return x > 0 && (x & (x - 1)) == 0; };
     pl->fast = pow2(d->Hs) && pow2(d->Ws) && d->Hs * d->Ws >= bkp && (d->R1 == 0 || d->R0 % 128 == 0) &&
-               msmall * (d->geom == ADN_GEMM_S1 ? 1 : 4) * (d->C0 > d->C1 ? d->C0 : d->C1) * esz < (1ll << 31) &&
-               msmall * (d->R0 > d->R1 ? d->R0 : d->R1) * esz < (1ll << 31);     // 32-bit scalar byte offsets
-    pl->mixed = pl->fast && d->C1 > 0 && (C < 128 || (d->C0 % 128) != 0);
+               (d->C1 == 0 || (d->C0 % 128 == 0 && C % 128 == 0)) &&
+               msmall * 4 * (d->C0 > d->C1 ? d->C0 : d->C1) * 4 < (1ll << 31) &&
+               msmall * (d->R0 > d->R1 ? d->R0 : d->R1) * 4 < (1ll << 31);     // 32-bit scalar byte offsets
     pl->steps = (int)adn_cdiv(msmall, bkp);
     pl->tiles_r = (int)adn_cdiv(R, 128);
-    pl->tiles_c = (int)adn_cdiv((int64_t)ntap * C, 128);
+    pl->tiles_c = 16 * C / 128;
     const int64_t tiles = (int64_t)pl->tiles_r * pl->tiles_c;
     int ns = (int)adn_cdiv(512, tiles);
     const int max_by_steps = pl->steps / 4 > 0 ? pl->steps / 4 : 1;
@@ -469,8 +429,6 @@ int wvalidate(const AdnWgradDesc* d) {
   ADN_CHECK_ARG((d->R1 == 0 || d->plain1) && (d->C1 == 0 || d->gath1), "adn_wgrad: null second source");
   ADN_CHECK_ARG((int64_t)d->B * d->Hs * d->Ws * 4 < (1ll << 31), "adn_wgrad: tensor too large");
   ADN_CHECK_ARG(d->c_valid >= 0 && d->c_valid <= d->C0 + d->C1, "adn_wgrad: bad c_valid %d", d->c_valid);
-  ADN_CHECK_ARG(d->geom == 0 || (d->geom == ADN_GEMM_S1 && (d->ks == 1 || d->ks == 3)), "adn_wgrad: bad geom/ks %d/%d",
-                d->geom, d->ks);
   return ADN_OK;
 }
 
@@ -484,36 +442,23 @@ int wrun(const AdnWgradDesc* d, const WPlan& pl, hipStream_t st) {
   p.out = pl.nsplit > 1 ? reinterpret_cast<float*>(d->workspace) : d->dw;
   p.out_elems = pl.out_elems;
   p.c_valid = d->c_valid > 0 ? d->c_valid : d->C0 + d->C1;
-  p.geom = d->geom;
-  p.ks = d->ks;
   if (pl.mfma) {
     constexpr int BKP = sizeof(T) == 2 ? 64 : 32;
     constexpr int stage = 4 * BKP * 128 * (int)sizeof(T);
     constexpr int epil = 128 * 132 * 4;
     constexpr int lds = stage > epil ? stage : epil;
-    const dim3 grid(pl.tiles_r * pl.tiles_c * pl.nsplit);
-    const bool s1 = d->geom == ADN_GEMM_S1;
-#define ADN_WG_LAUNCH(FAST_, MIXED_, S1_)                                                                      \
-  do {                                                                                                         \
-    static bool attr_set = false;                                                                              \
-    if (!attr_set) {                                                                                           \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_kernel<T, FAST_, MIXED_, S1_>),      \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);                              \
-      attr_set = true;                                                                                         \
-    }                                                                                                          \
-    hipLaunchKernelGGL((wgrad_mfma_kernel<T, FAST_, MIXED_, S1_>), grid, dim3(256), lds, st, p);               \
-  } while (0)
-    if (pl.fast && pl.mixed) {
-      if (s1) ADN_WG_LAUNCH(true, true, true);
-      else ADN_WG_LAUNCH(true, true, false);
-    } else if (pl.fast) {
-      if (s1) ADN_WG_LAUNCH(true, false, true);
-      else ADN_WG_LAUNCH(true, false, false);
-    } else {
-      if (s1) ADN_WG_LAUNCH(false, false, true);
-      else ADN_WG_LAUNCH(false, false, false);
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_kernel<T, true>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_kernel<T, false>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr_set = true;
     }
-#undef ADN_WG_LAUNCH
+    if (pl.fast)
+      hipLaunchKernelGGL((wgrad_mfma_kernel<T, true>), dim3(pl.tiles_r * pl.tiles_c * pl.nsplit), dim3(256), lds, st, p);
+    else
+      hipLaunchKernelGGL((wgrad_mfma_kernel<T, false>), dim3(pl.tiles_r * pl.tiles_c * pl.nsplit), dim3(256), lds, st, p);
   } else {
     hipLaunchKernelGGL((wgrad_direct_kernel<T>), dim3((unsigned)adn_cdiv(pl.out_elems, 256), pl.nsplit), dim3(256),
                        0, st, p, pl.pix_per_split);
@@ -531,21 +476,16 @@ int wrun(const AdnWgradDesc* d, const WPlan& pl, hipStream_t st) {
 
 }  // namespace
 
-int64_t adn_wgrad_k4_workspace_bytes(const AdnWgradDesc* d);   // wgrad_k4.hip
-int adn_wgrad_k4(const AdnWgradDesc* d, void* stream);
-
-extern "C" int64_t adn_wgrad_workspace_bytes(const AdnWgradDesc* d) {
+int64_t adn_wgrad_k4_workspace_bytes(const AdnWgradDesc* d) {
   if (wvalidate(d) != ADN_OK) return -1;
-  if (d->geom != ADN_GEMM_S1) return adn_wgrad_k4_workspace_bytes(d);
   WPlan pl;
   make_wplan(d, &pl);
   return pl.slab_bytes;
 }
 
-extern "C" int adn_wgrad(const AdnWgradDesc* d, void* stream) {
+int adn_wgrad_k4(const AdnWgradDesc* d, void* stream) {
   int rc = wvalidate(d);
   if (rc != ADN_OK) return rc;
-  if (d->geom != ADN_GEMM_S1) return adn_wgrad_k4(d, stream);
   WPlan pl;
   make_wplan(d, &pl);
   ADN_CHECK_ARG(pl.slab_bytes == 0 || (d->workspace && d->workspace_bytes >= pl.slab_bytes),
