@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 from . import kernels as K
-from .dc_engine import Act, ConvBNReLU, DCEngine, Head1x1, Op
+from .dc_engine import Act, ConvBNReLU, DCEngine, Head1x1, Op, flag_solo
 from ._lib import EPI_ACT, EPI_ADD, GEMM_S1
 
 
@@ -221,9 +221,7 @@ class AdaBinsEngine(DCEngine):
                         acts[id(a)] = a
             br.acts = list(acts.values())
             for a in br.acts:
-                prod = a.producer
-                a.fused_bwd = (a.needs_grad and isinstance(prod, ConvBNReLU) and len(a.consumers) == 1 and
-                               isinstance(a.consumers[0], ConvBNReLU) and len(a.consumers[0].srcs) == 1)
+                flag_solo(a)
                 a.alloc(B, self.dtype, dev)
             for op in allops + [br.head]:
                 op.prepare(self)
@@ -319,12 +317,12 @@ class AdaBinsEngine(DCEngine):
 def _update_again(self, eng):
     """Second running-statistics update of a decoder BatchNorm with the same batch statistics."""
     bn, o = self.bn, self.out
-    track = bn.track_running_stats and bn.running_mean is not None
-    if not track:
+    gamma, beta, rmean, rvar, _ = self._bn_vectors()
+    if rmean is None:
         return
-    K.bn_fwd_finalize(self.part, self.P, self.N, eng.B * o.H * o.W, bn.weight, bn.bias, bn.eps,
-                      0.1 if bn.momentum is None else bn.momentum, bn.running_mean, bn.running_var,
-                      bn.num_batches_tracked, o.mean, o.istd, self.scale, self.shift)
+    K.bn_fwd_finalize(self.part, self.P, self.N, eng.B * o.H * o.W, gamma, beta, bn.eps,
+                      0.1 if bn.momentum is None else bn.momentum, rmean, rvar, bn.num_batches_tracked, o.mean, o.istd,
+                      self.scale, self.shift)
 
 
 ConvBNReLU.update_running_stats_again = _update_again

@@ -424,8 +424,9 @@ void make_wplan(const AdnWgradDesc* d, WPlan* pl) {
   pl->out_elems = (int64_t)R * ntap * cv;
   const int epc = d->dtype == ADN_BF16 ? 8 : 4;
   // sources are selected per 16-byte chunk, so a tile may straddle the two plain / gathered sources
-  const bool aligned = (R % 64 == 0) && (d->R0 % epc == 0) && (C % epc == 0) && (d->C0 % epc == 0) &&
-                       (C >= 128 ? (C % 128 == 0) : (128 % C == 0));
+  // tap, channel and source are per-lane constants of a 16-byte chunk, so a 128-column tile may straddle taps
+  // (C = 192, 96, ...) as well as the two gathered sources; only chunks must not straddle anything
+  const bool aligned = (R % 64 == 0) && (d->R0 % epc == 0) && (C % epc == 0) && (d->C0 % epc == 0);
   pl->mfma = aligned;
   pl->fast = false;
   pl->mixed = false;
@@ -436,7 +437,7 @@ void make_wplan(const AdnWgradDesc* d, WPlan* pl) {
     pl->fast = pow2(d->Hs) && pow2(d->Ws) && d->Hs * d->Ws >= bkp && (d->R1 == 0 || d->R0 % 128 == 0) &&
                msmall * (d->geom == ADN_GEMM_S1 ? 1 : 4) * (d->C0 > d->C1 ? d->C0 : d->C1) * esz < (1ll << 31) &&
                msmall * (d->R0 > d->R1 ? d->R0 : d->R1) * esz < (1ll << 31);     // 32-bit scalar byte offsets
-    pl->mixed = pl->fast && d->C1 > 0 && (C < 128 || (d->C0 % 128) != 0);
+    pl->mixed = pl->fast && d->C1 > 0 && (C % 128 != 0 || (d->C0 % 128) != 0);
     pl->steps = (int)adn_cdiv(msmall, bkp);
     pl->tiles_r = (int)adn_cdiv(R, 128);
     pl->tiles_c = (int)adn_cdiv((int64_t)ntap * C, 128);

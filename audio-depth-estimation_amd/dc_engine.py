@@ -97,27 +97,49 @@ class ConvBNReLU(Op):
     def prepare(self, eng):
         T, dev, B = eng.dtype, eng.dev, eng.B
         o = self.out
-        N = o.C
+        N = o.C                                       # as the kernels see it (a solo mid tensor may be zero padded)
         self.N = N
+        self.n_real = getattr(o, 'C_real', N)
+        self.padded = self.n_real != N
         self.cin_real = sum(s.C_real if hasattr(s, 'C_real') else s.C for s in self.srcs)
         self.c0 = self.srcs[0].C
         self.c1 = self.srcs[1].C if len(self.srcs) > 1 else 0
-        cin = self.c0 + self.c1                       # as the kernels see it (thin inputs are zero padded)
+        cin = self.c0 + self.c1                       # as the kernels see it (thin / padded inputs carry zero channels)
+        assert all(not hasattr(s, 'C_real') for s in self.srcs[:-1]), 'a padded source must be the last one'
         taps = self.ks * self.ks
         w = self.conv.weight
-        assert w.shape[1] == self.cin_real and w.shape[0] == N
+        assert w.shape[1] == self.cin_real and w.shape[0] == self.n_real
         f32 = dict(dtype=torch.float32, device=dev)
         # forward operand [N][row stride]: the parameter memory itself when rows need no padding
         rs = K.s1_row_stride(T, taps, cin)
-        self.fwd_is_view = (rs == taps * self.cin_real)
+        self.fwd_is_view = (rs == taps * self.cin_real) and not self.padded
         if self.fwd_is_view:
             src = eng.flat_p if T == torch.float32 else eng.flat_w16
             self.w_fwd = eng._flat_slice(src, w).view(N, rs)
         else:
-            self.w_fwd = torch.empty(N, rs, dtype=T, device=dev)
-        # input-gradient operand [Cin][row stride'] (flipped taps, transposed channels)
+            self.w_fwd = torch.zeros(N, rs, dtype=T, device=dev)
+        # input-gradient operand [Cin][row stride'] (flipped taps, transposed channels); rows of padded inputs stay 0
         self.need_dgrad = any(s.needs_grad for s in self.srcs)
-        self.w_dg = torch.empty(cin, K.s1_row_stride(T, taps, N), dtype=T, device=dev) if self.need_dgrad else None
+        self.w_dg = torch.zeros(cin, K.s1_row_stride(T, taps, N), dtype=T, device=dev) if self.need_dgrad else None
+        if self.padded:
+            # Output channels zero-padded to a multiple of 64 so that the layer runs on the MFMA kernels: padded f32
+            # master [N][taps][cin_real] (extra rows 0), padded BN vectors (gamma = beta = 0 -> the extra channels are
+            # exactly 0 forward and backward), running statistics re-homed into padded buffers of which the module's
+            # buffers become views, temporaries for the gradients.
+            bn = self.bn
+            self.wm_p = torch.zeros(N, taps * self.cin_real, **f32)
+            self.gamma_p, self.beta_p = torch.zeros(N, **f32), torch.zeros(N, **f32)
+            self.bias_p = torch.zeros(N, **f32) if self.conv.bias is not None else None
+            self.dgamma_p, self.dbeta_p = torch.empty(N, **f32), torch.empty(N, **f32)
+            self.dw_p = torch.empty(N, taps * self.cin_real, **f32) if o.needs_grad else None
+            if bn.track_running_stats and bn.running_mean is not None:
+                rm, rv = torch.zeros(N, **f32), torch.ones(N, **f32)
+                rm[:self.n_real].copy_(bn.running_mean)
+                rv[:self.n_real].copy_(bn.running_var)
+                bn.running_mean, bn.running_var = rm[:self.n_real], rv[:self.n_real]
+                self.rm_p, self.rv_p = rm, rv
+            else:
+                self.rm_p = self.rv_p = None
         o.z = torch.empty_like(o.data)
         o.mean, o.istd = torch.empty(N, **f32), torch.empty(N, **f32)
         self.scale, self.shift = torch.empty(N, **f32), torch.empty(N, **f32)
@@ -148,10 +170,26 @@ class ConvBNReLU(Op):
         w = self.conv.weight
         taps = self.ks * self.ks
         master = eng._flat_slice(eng.flat_p, w)
+        if self.padded:
+            nr = self.n_real
+            K.pack_rows(master, nr, 1, taps * self.cin_real, self.wm_p[:nr])          # rows nr..N stay zero
+            K.pack_rows(eng._flat_slice(eng.flat_p, self.bn.weight), nr, 1, 1, self.gamma_p[:nr])
+            K.pack_rows(eng._flat_slice(eng.flat_p, self.bn.bias), nr, 1, 1, self.beta_p[:nr])
+            if self.bias_p is not None:
+                K.pack_rows(eng._flat_slice(eng.flat_p, self.conv.bias), nr, 1, 1, self.bias_p[:nr])
+            master = self.wm_p
         if not self.fwd_is_view:
             K.pack_rows(master, self.N, taps, self.cin_real, self.w_fwd, y_pad=self.c0 + self.c1)
         if self.w_dg is not None:
             K.pack_transpose_taps(master, self.N, taps, self.cin_real, self.w_dg, flip=True)
+
+    def _bn_vectors(self):
+        """(gamma, beta, running_mean, running_var, conv bias) as the kernels see them (padded copies when padded)."""
+        bn = self.bn
+        if self.padded:
+            return self.gamma_p, self.beta_p, self.rm_p, self.rv_p, self.bias_p
+        track = bn.track_running_stats and bn.running_mean is not None
+        return bn.weight, bn.bias, bn.running_mean if track else None, bn.running_var if track else None, self.conv.bias
 
     def fwd(self, eng, training):
         T, B, o = eng.dtype, eng.B, self.out
@@ -159,20 +197,20 @@ class ConvBNReLU(Op):
         in1 = self.srcs[1].data if self.c1 else None
         bn, N = self.bn, self.N
         pixels = B * o.H * o.W
+        gamma, beta, rmean, rvar, cbias = self._bn_vectors()
         if training:
             K.igemm(T, GEMM_S1, B, o.H, o.W, in0, in1, self.w_fwd, N, EPI_Z_STATS,
-                    [K.Seg(N, out0=o.z, partials=self.part, bias=self.conv.bias)], eng.workspace,
+                    [K.Seg(N, out0=o.z, partials=self.part, bias=cbias)], eng.workspace,
                     algo_c=self.cin_real, ks=self.ks)
-            track = bn.track_running_stats and bn.running_mean is not None
-            K.bn_fwd_finalize(self.part, self.P, N, pixels, bn.weight, bn.bias, bn.eps,
-                              BN_MOMENTUM if bn.momentum is None else bn.momentum,
-                              bn.running_mean if track else None, bn.running_var if track else None,
-                              bn.num_batches_tracked if track else None, o.mean, o.istd, self.scale, self.shift)
+            K.bn_fwd_finalize(self.part, self.P, N, pixels, gamma, beta, bn.eps,
+                              BN_MOMENTUM if bn.momentum is None else bn.momentum, rmean, rvar,
+                              bn.num_batches_tracked if rmean is not None else None, o.mean, o.istd, self.scale,
+                              self.shift)
             K.bn_act(o.z, pixels, N, self.scale, self.shift, 0.0, None, o.data)
         else:
-            K.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, self.scale, self.shift)
-            if self.conv.bias is not None:                    # BN(conv + b) = conv * scale + (shift + b * scale)
-                self.shift.addcmul_(self.conv.bias.detach(), self.scale)
+            K.bn_eval_affine(gamma, beta, rmean, rvar, bn.eps, self.scale, self.shift)
+            if cbias is not None:                             # BN(conv + b) = conv * scale + (shift + b * scale)
+                self.shift.addcmul_(cbias.detach(), self.scale)
             K.igemm(T, GEMM_S1, B, o.H, o.W, in0, in1, self.w_fwd, N, EPI_ACT,
                     [K.Seg(N, out1=o.data, scale=self.scale, shift=self.shift)], eng.workspace,
                     algo_c=self.cin_real, ks=self.ks)
@@ -184,8 +222,13 @@ class ConvBNReLU(Op):
         G = o.grad
         if not o.fused_bwd:
             K.relu_bwd_stats(G, o.data, o.z, o.mean, o.istd, pixels, N, o.bpart)
-        K.bn_bwd_finalize(o.bpart, o.bpart_rows, N, pixels, eng._flat_slice(eng.flat_g, bn.weight),
-                          eng._flat_slice(eng.flat_g, bn.bias), self.coef)
+        fg = lambda p: eng._flat_slice(eng.flat_g, p)
+        if self.padded:
+            K.bn_bwd_finalize(o.bpart, o.bpart_rows, N, pixels, self.dgamma_p, self.dbeta_p, self.coef)
+            K.pack_rows(self.dgamma_p[:self.n_real], self.n_real, 1, 1, fg(bn.weight))
+            K.pack_rows(self.dbeta_p[:self.n_real], self.n_real, 1, 1, fg(bn.bias))
+        else:
+            K.bn_bwd_finalize(o.bpart, o.bpart_rows, N, pixels, fg(bn.weight), fg(bn.bias), self.coef)
         K.bn_bwd_apply(G, o.z, pixels, N, self.scale, o.mean, o.istd, self.coef)      # G is now d loss / d z
         eng._mark(bn.weight, bn.bias)
         if self.conv.bias is not None:
@@ -195,8 +238,13 @@ class ConvBNReLU(Op):
             eng._mark(self.conv.bias)
         in0 = self.srcs[0].data
         in1 = self.srcs[1].data if self.c1 else None
-        K.wgrad(T, B, o.H, o.W, G, None, in0, in1, eng._flat_slice(eng.flat_g, self.conv.weight), eng.workspace,
-                c_valid=self.c_valid, ks=self.ks)
+        if self.padded:
+            K.wgrad(T, B, o.H, o.W, G, None, in0, in1, self.dw_p, eng.workspace, c_valid=self.c_valid, ks=self.ks)
+            nr, row = self.n_real, self.dw_p.shape[1]
+            K.pack_rows(self.dw_p[:nr], nr, 1, row, fg(self.conv.weight).view(nr, row))
+        else:
+            K.wgrad(T, B, o.H, o.W, G, None, in0, in1, fg(self.conv.weight), eng.workspace, c_valid=self.c_valid,
+                    ks=self.ks)
         eng._ready(self.conv.weight)
         if not self.need_dgrad:
             return
@@ -385,6 +433,20 @@ class CrossAttention(Op):
         eng._ready(m.query.weight)
 
 
+def flag_solo(a):
+    """Mark an activation whose only consumer is a single-source conv (the mid tensor of a DoubleConv): the consumer's
+    dgrad epilogue applies its ReLU mask + BN statistics, and -- nobody else looking at it -- its channel count may be
+    zero-padded to a multiple of 64 to reach the MFMA kernels (96 -> 128 in the AdaBins decoder, 32 -> 64 at narrow
+    widths)."""
+    prod = a.producer
+    solo = (isinstance(prod, ConvBNReLU) and len(a.consumers) == 1 and isinstance(a.consumers[0], ConvBNReLU) and
+            len(a.consumers[0].srcs) == 1)
+    a.fused_bwd = solo and a.needs_grad
+    if solo and a.C % 64 != 0 and a.C >= 32 and a.data is None and not hasattr(a, 'C_real'):
+        a.C_real = a.C
+        a.C = (a.C + 63) // 64 * 64
+
+
 class DCEngine(FlatParamEngine):
     """Runs a DoubleConv-family module through libadn.  ``build(engine, B, C, H, W)`` (supplied by the model
     mirror) returns (inputs, ops, head): ``inputs`` = [(Act, first channel, channels)] slices of the NCHW network
@@ -430,9 +492,7 @@ class DCEngine(FlatParamEngine):
         for a, b in self.pairs:                       # inputs of an aliasing pair are stacked before its outputs
             stack_pair(a, b, B, self.dtype, x.device)
         for a in self.acts:
-            prod = a.producer
-            a.fused_bwd = (isinstance(prod, ConvBNReLU) and len(a.consumers) == 1 and
-                           isinstance(a.consumers[0], ConvBNReLU) and len(a.consumers[0].srcs) == 1)
+            flag_solo(a)
             a.alloc(B, self.dtype, x.device)
         ws = 16
         for op in self.ops + [self.head]:

@@ -51,6 +51,10 @@ S1_SHAPES = [
     (4, 128, 128, 64, 64, 64, 3),   # 256-row tiles
     (2, 64, 64, 64, 64, 64, 3),     # RGBDepthNet up4.conv1 at 64x64 (split-K, two segments in the dgrad)
     (2, 128, 0, 64, 32, 32, 3),     # up3.conv2
+    (2, 64, 128, 128, 16, 16, 3),   # AdaBins up4.conv1: C = 192, column tiles straddle taps AND sources
+    (2, 192, 0, 128, 8, 8, 3),      # AdaBins up3.conv2: single source, C = 192
+    (2, 96, 0, 64, 16, 16, 3),      # 96 channels: per-lane taps in the forward loader and in wgrad
+    (3, 128, 256, 192, 6, 10, 3),   # AdaBins up3.conv1 (N = 192), non power-of-two image (slow wgrad path)
     (2, 8, 0, 64, 16, 16, 3),       # thin input: narrow loader, K = 72 padded to the K-step
     (2, 16, 0, 64, 7, 9, 3),        # narrow, odd sizes
     (2, 6, 0, 10, 5, 5, 3),         # generic direct path

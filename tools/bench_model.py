@@ -16,9 +16,53 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 
+def adabins_main(args, dev, dtype, gt, g):
+    from audio_depth_estimation_amd import _lib
+    from audio_depth_estimation_amd.adabins_engine import AdaBinsTrainer
+    from audio_depth_estimation_amd.models.adabins_distillation_model import AdaBinsDistillationModel
+    B, S = args.batch, args.size
+    model = AdaBinsDistillationModel(128, 64, S, 30.0)
+    model.compute_dtype = dtype
+    model = model.to(dev).train()
+    audio, rgb = torch.rand(B, 2, S, S, generator=g).to(dev), torch.rand(B, 3, S, S, generator=g).to(dev)
+    gt[gt < 3] = 0
+    tr = AdaBinsTrainer(model.engine(), lr=1e-4)
+    for _ in range(2):
+        tr.step(audio, rgb, gt)
+    torch.cuda.synchronize()
+    _lib.RECORD = []
+    tr.step(audio, rgb, gt)
+    plan, _lib.RECORD = _lib.RECORD, None
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in plan]
+    fam = {}
+    for i, (fn, a, name, meta) in enumerate(plan):
+        evs[i][0].record()
+        a() if fn is None else fn(*a)
+        evs[i][1].record()
+    torch.cuda.synchronize()
+    for i, (fn, a, name, meta) in enumerate(plan):
+        acc = fam.setdefault(name, [0.0, 0.0, 0])
+        acc[0] += evs[i][0].elapsed_time(evs[i][1])
+        acc[1] += meta.get('flops', 0.0)
+        acc[2] += 1
+    print(f'{"entry point":34s} {"ms/step":>9s} {"launches":>9s} {"TFLOP/s":>9s}')
+    for name, (ms, fl, n) in sorted(fam.items(), key=lambda kv: -kv[1][0]):
+        tf = f'{fl / (ms * 1e-3) / 1e12:9.1f}' if fl else '         '
+        print(f'{name:34s} {ms:9.3f} {n:9d} {tf}')
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = tr.step(audio, rgb, gt)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    print(json.dumps({'model': 'adabins', 'batch': B, 'size': S, 'dtype': args.dtype, 'ms_per_step': 1e3 * el / args.steps,
+                      'depth_maps_per_s': B * args.steps / el, 'gemm_gflop_per_step': sum(v[1] for v in fam.values()) / 1e9,
+                      'loss': float(loss), 'mem_gb': torch.cuda.max_memory_allocated() / 2 ** 30}))
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--model', default='rgb', choices=['rgb', 'binaural'])
+    ap.add_argument('--model', default='rgb', choices=['rgb', 'binaural', 'adabins'])
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--base', type=int, default=64)
@@ -39,13 +83,15 @@ def main():
         x = torch.rand(B, 3, S, S, generator=g).to(dev)
         trainer_args = dict(criterion='DepthLoss', l1_weight=1.0, silog_weight=0.1, optimizer='AdamW', lr=1e-4,
                             weight_decay=0.01, clip_norm=None)
-    else:
+    elif args.model == 'binaural':
         from audio_depth_estimation_amd.models.binaural_attention_model import BinauralAttentionDepthNet
         model = BinauralAttentionDepthNet(args.base, True, S, 30.0)
         x = torch.rand(B, 2, S, S, generator=g).to(dev)
         gt[gt < 3] = 0
         trainer_args = dict(criterion='L1', optimizer='AdamW', lr=1e-3, weight_decay=0.01, clip_norm=None,
                             mask_mode='gt0')
+    if args.model == 'adabins':
+        return adabins_main(args, dev, dtype, gt, g)
     model.compute_dtype = dtype
     model = model.to(dev).train()
     tr = FusedTrainer(model.engine(), **trainer_args)
