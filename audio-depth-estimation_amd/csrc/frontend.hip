@@ -240,3 +240,44 @@ extern "C" int adn_resize_bilinear(const float* src, int32_t planes, int32_t H, 
   ADN_CHECK_LAUNCH();
   return ADN_OK;
 }
+
+// ---- depth-target preparation (BatvisionV2_Dataset.py:65-78, BatvisionV1_Dataset.py:45-64) -------------------------
+// raw depth in millimetres (f32 / u16 / i32) -> metres, NaN / +-inf -> 0, clip to max_depth (when > 0), negatives -> 0,
+// cv2.INTER_NEAREST resize (source index = min(floor(dst * in / out), in - 1)), optional / norm.
+template <typename S>
+__global__ __launch_bounds__(256) void depth_prepare_kernel(const S* src, int planes, int H, int W, int So, float maxd,
+                                                            float norm, float* out) {
+  const int64_t n = (int64_t)planes * So * So;
+  const double sy = (double)H / So, sx = (double)W / So;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const int x = (int)(e % So), y = (int)((e / So) % So);
+    const int64_t pl = e / ((int64_t)So * So);
+    int iy = (int)floor(y * sy), ix = (int)floor(x * sx);
+    iy = iy < H - 1 ? iy : H - 1;
+    ix = ix < W - 1 ? ix : W - 1;
+    float d = (float)src[(pl * H + iy) * W + ix];
+    if (!(d == d) || d == INFINITY || d == -INFINITY) d = 0.f;
+    d = d / 1000.0f;
+    if (maxd > 0.f && d > maxd) d = maxd;
+    if (d < 0.f) d = 0.f;
+    out[e] = norm > 0.f ? d / norm : d;
+  }
+}
+
+extern "C" int adn_depth_prepare(const void* src, int32_t src_type, int32_t planes, int32_t H, int32_t W, int32_t S,
+                                 float max_depth, float norm, float* out, void* stream) {
+  ADN_CHECK_ARG(src && out && planes > 0 && H > 0 && W > 0 && S > 0, "adn_depth_prepare: bad arguments");
+  ADN_CHECK_ARG(src_type >= 0 && src_type <= 2, "adn_depth_prepare: src_type %d (0 f32, 1 u16, 2 i32)", src_type);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int64_t blocks = adn_cdiv((int64_t)planes * S * S, 256);
+  if (blocks > 4096) blocks = 4096;
+  const dim3 grid((unsigned)blocks);
+  if (src_type == 0)
+    hipLaunchKernelGGL((depth_prepare_kernel<float>), grid, dim3(256), 0, st, reinterpret_cast<const float*>(src), planes, H, W, S, max_depth, norm, out);
+  else if (src_type == 1)
+    hipLaunchKernelGGL((depth_prepare_kernel<uint16_t>), grid, dim3(256), 0, st, reinterpret_cast<const uint16_t*>(src), planes, H, W, S, max_depth, norm, out);
+  else
+    hipLaunchKernelGGL((depth_prepare_kernel<int32_t>), grid, dim3(256), 0, st, reinterpret_cast<const int32_t*>(src), planes, H, W, S, max_depth, norm, out);
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}

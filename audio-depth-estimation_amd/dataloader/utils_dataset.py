@@ -93,3 +93,23 @@ class GpuAudioFrontend:
         out = torch.empty(B, 2, self.size, self.size, dtype=torch.float32, device=wave.device)
         K.frontend(wave, self.mode, self.size, self.antialias, out, self._ws)
         return out
+
+
+class GpuDepthTarget:
+    """Batched depth-target preparation on the device: raw depth maps in millimetres [B,H,W]
+    (float32 / uint16 / int32 device tensors) -> [B,1,S,S] f32 metres, exactly the arithmetic of
+    BatvisionV2_Dataset.__getitem__ (:65-78) / BatvisionV1_Dataset (:45-64): NaN, inf -> 0; / 1000; clip to max_depth;
+    negatives -> 0; cv2.INTER_NEAREST resize; / max_depth when ``depth_norm`` (BV1 :63-64).  DataLoader workers then
+    only read files."""
+
+    def __init__(self, size, max_depth, depth_norm=False):
+        self.size, self.max_depth, self.depth_norm = size, max_depth, depth_norm
+
+    def __call__(self, raw):
+        from .. import kernels as K
+        if not raw.is_cuda:
+            raise RuntimeError('GpuDepthTarget runs on libadn HIP kernels only (no CPU path)')
+        raw = raw.contiguous()
+        out = torch.empty(raw.shape[0], 1, self.size, self.size, dtype=torch.float32, device=raw.device)
+        K.depth_prepare(raw, self.size, self.max_depth, self.max_depth if self.depth_norm else 0.0, out)
+        return out

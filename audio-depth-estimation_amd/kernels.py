@@ -565,3 +565,12 @@ def distill_small(mean_s, mean_t, cent_s, cent_t, feat_stats, feat_channels, pix
     (d.lambda_task, d.lambda_response, d.lambda_feature, d.lambda_bin, d.lambda_sparse) = [float(v) for v in lambdas]
     d.terms, d.dmean, d.dcent = ptr(terms), ptr(dmean), ptr(dcent)
     _lib.call('adn_distill_small', C.byref(d), _stream())
+
+
+def depth_prepare(src, S, max_depth, norm, out):
+    """Raw depth maps in mm [planes,H,W] (float32 / uint16 / int32) -> metres, cleaned, clipped, nearest-resized."""
+    code = {torch.float32: 0, torch.uint16: 1, torch.int32: 2}[src.dtype]
+    planes, H, W = src.shape
+    _dev(src, out)
+    _lib.call('adn_depth_prepare', ptr(src), code, planes, H, W, S, float(max_depth or 0.0), float(norm or 0.0), ptr(out),
+              _stream())

@@ -386,6 +386,12 @@ int64_t adn_frontend_workspace_bytes(int32_t B, int32_t T, int32_t mode);
 int adn_frontend(const float* wave, int32_t B, int32_t T, int32_t mode, int32_t S,
                  int32_t antialias, float* out, void* workspace, int64_t workspace_bytes,
                  void* stream);
+/* Depth-target preparation on the device (BatvisionV2_Dataset.py:65-78, BatvisionV1_Dataset.py:45-64): src = raw
+ * depth maps in millimetres [planes][H][W] (src_type 0 f32, 1 u16, 2 i32) -> out f32 [planes][S][S] in metres: NaN and
+ * +-inf -> 0, clip to max_depth (if > 0), negatives -> 0, cv2.INTER_NEAREST resize, then / norm if norm > 0
+ * (depth_norm: norm = max_depth). */
+int adn_depth_prepare(const void* src, int32_t src_type, int32_t planes, int32_t H, int32_t W, int32_t S,
+                      float max_depth, float norm, float* out, void* stream);
 /* transforms.Resize((S,S)) alone (utils_dataset.py:18-20): src f32 [planes][H][W] -> out [planes][S][S]. */
 int adn_resize_bilinear(const float* src, int32_t planes, int32_t H, int32_t W, int32_t S,
                         int32_t antialias, float* out, void* stream);

@@ -129,3 +129,37 @@ def test_frontend_impulse_bin_indexing_exact():
     lit = np.nonzero(spec[0, 5] > 1e-7)[0]
     expect = [t for t in range(nT) if 0 < n0 + 256 - (t * 16 + 224) < 64]       # Hann tap j=0 is exactly 0
     assert list(lit) == expect
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.uint16, torch.int32])
+@pytest.mark.parametrize('norm', [False, True])
+def test_depth_target_preparation(dt, norm):
+    """GpuDepthTarget == the depth branch of BatvisionV2_Dataset.__getitem__ (:65-78) / BatvisionV1 (:45-64), restated on
+    the host with numpy (mm -> m, NaN/inf -> 0, clip, negatives -> 0, cv2.INTER_NEAREST index rule): bit exact."""
+    from audio_depth_estimation_amd.dataloader.utils_dataset import GpuDepthTarget, resize_nearest_cv2
+    rng = np.random.default_rng(0)
+    B, H, W, S, maxd = 3, 720, 1280, 256, 30.0
+    raw = rng.integers(0, 60000, size=(B, H, W)).astype(np.float64)
+    if dt == torch.float32:
+        raw[0, :5, :5] = np.nan
+        raw[1, 7, 9] = np.inf
+        raw[2, 100, 100] = -np.inf
+        raw[0, 300:310, :] = -50.0
+        src = raw.astype(np.float32)
+    elif dt == torch.uint16:
+        src = raw.astype(np.uint16)
+    else:
+        src = raw.astype(np.int32)
+        src[0, 300:310, :] = -50
+    want = []
+    for b in range(B):
+        d = np.nan_to_num(src[b].astype(np.float32))
+        d[np.isinf(src[b].astype(np.float32))] = 0
+        d = d / np.float32(1000.0)
+        d[d > maxd] = maxd
+        d[d < 0] = 0
+        d = resize_nearest_cv2(d, S)
+        want.append(d / np.float32(maxd) if norm else d)
+    got = GpuDepthTarget(S, maxd, depth_norm=norm)(torch.from_numpy(src).to('cuda'))
+    assert got.shape == (B, 1, S, S)
+    np.testing.assert_array_equal(got[:, 0].cpu().numpy(), np.stack(want))
