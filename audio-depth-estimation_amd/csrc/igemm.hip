@@ -539,7 +539,7 @@ bool make_plan(const AdnIgemmDesc* d, Plan* pl) {
   const int64_t tiles = (int64_t)pl->tiles_m * pl->tiles_n * pl->phases;
   int ns = 1;
   if (tiles < 256) {
-    ns = (int)adn_cdiv(512, tiles);
+    ns = (int)(512 / tiles);          // stay within one resident wave of workgroups (256 CUs x 2)
     const int max_by_k = pl->ksteps / 2 > 0 ? pl->ksteps / 2 : 1;
     if (ns > max_by_k) ns = max_by_k;
     if (ns > 64) ns = 64;

@@ -442,7 +442,8 @@ void make_wplan(const AdnWgradDesc* d, WPlan* pl) {
     pl->tiles_r = (int)adn_cdiv(R, 128);
     pl->tiles_c = (int)adn_cdiv((int64_t)ntap * C, 128);
     const int64_t tiles = (int64_t)pl->tiles_r * pl->tiles_c;
-    int ns = (int)adn_cdiv(512, tiles);
+    // one resident wave of workgroups: 256 CUs x 2 workgroups; never 513 (9 taps x 57 splits ran a 2x tail)
+    int ns = (int)(512 / tiles);
     const int max_by_steps = pl->steps / 4 > 0 ? pl->steps / 4 : 1;
     if (ns > max_by_steps) ns = max_by_steps;
     if (ns > 256) ns = 256;
