@@ -9,6 +9,7 @@
 //   featcos_*      1 - mean cosine similarity of spatially normalised features, per encoder level
 //   distill_small  KL of the temperature-softened mean logits, bin-centre MSE, assembly of the total loss
 #include "adn_common.h"
+#include "epilogue.h"
 
 namespace {
 
@@ -36,9 +37,55 @@ __device__ __forceinline__ float block_max(float v, float* sm) {
 // NQ = 1: sum x;  NQ = 3 (second tensor y): sum x^2, sum y^2, sum x*y
 template <typename T, int NQ>
 __global__ __launch_bounds__(256) void rowsum_partial(const void* x, const void* y, int HW, int C, int ld, float* partial) {
+  __shared__ float red[256 * 8 * NQ];
   const int b = blockIdx.y, P = gridDim.x;
   const int rpb = (HW + P - 1) / P;
   const int r0 = blockIdx.x * rpb, r1 = r0 + rpb < HW ? r0 + rpb : HW;
+  float* po = partial + (((int64_t)b * P + blockIdx.x) * NQ) * C;
+  if ((C & 7) == 0 && (ld & 7) == 0 && C <= 2048) {
+    // 8 channels per thread, 256 / (C/8) rows per iteration, cross-row-group reduction through LDS
+    const int ncg = C >> 3;
+    const int rpi = 256 / ncg;
+    const int r = threadIdx.x / ncg, cg = threadIdx.x - r * ncg;
+    float s[NQ][8];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s[q][k] = 0.f;
+    if (r < rpi) {
+      for (int row = r0 + r; row < r1; row += rpi) {
+        const int64_t e = ((int64_t)b * HW + row) * ld + cg * 8;
+        float a[8];
+        load8<T>(x, e, a);
+        if constexpr (NQ == 1) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) s[0][k] += a[k];
+        } else {
+          float q8[8];
+          load8<T>(y, e, q8);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            s[0][k] += a[k] * a[k];
+            s[NQ - 2][k] += q8[k] * q8[k];
+            s[NQ - 1][k] += a[k] * q8[k];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) red[(threadIdx.x * NQ + q) * 8 + k] = s[q][k];
+    __syncthreads();
+    for (int t = threadIdx.x; t < NQ * C; t += 256) {
+      const int q = t / C, c = t - q * C;
+      const int g = c >> 3, k = c & 7;
+      float a = 0.f;
+      for (int rr = 0; rr < rpi; ++rr) a += red[((rr * ncg + g) * NQ + q) * 8 + k];
+      po[(int64_t)q * C + c] = a;
+    }
+    return;
+  }
   for (int c = threadIdx.x; c < C; c += 256) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     for (int r = r0; r < r1; ++r) {
@@ -52,11 +99,10 @@ __global__ __launch_bounds__(256) void rowsum_partial(const void* x, const void*
         s2 += a * q;
       }
     }
-    float* po = partial + (((int64_t)b * P + blockIdx.x) * NQ) * C + c;
-    po[0] = s0;
+    po[c] = s0;
     if (NQ == 3) {
-      po[C] = s1;
-      po[2 * C] = s2;
+      po[C + c] = s1;
+      po[2 * C + c] = s2;
     }
   }
 }

@@ -13,6 +13,7 @@
 // one wave per query (forward, dQ) or per key (dK/dV), 64 keys / queries per inner step, probabilities
 // exchanged through LDS.  The bf16 MFMA kernels for the full-width head dims live in attn_mfma.hip.
 #include "adn_common.h"
+#include "epilogue.h"
 
 namespace {
 
@@ -217,15 +218,48 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_generic(AttnParams p) {
 }
 
 // ---- per-channel sums of a [rows][ld] tensor (bias gradients of the 1x1 projections) -----------------------
+// 8 channels (16/32 bytes) per thread, 256 / (C/8) rows per iteration, cross-row-group reduction through LDS.
 template <typename T>
 __global__ __launch_bounds__(256) void channel_sum_partial(const void* x, int64_t rows, int C, int ld, float* partials) {
+  __shared__ float red[256 * 8];
   const int64_t rpb = (rows + gridDim.x - 1) / gridDim.x;
   const int64_t r0 = (int64_t)blockIdx.x * rpb;
   const int64_t r1 = r0 + rpb < rows ? r0 + rpb : rows;
-  for (int c = threadIdx.x; c < C; c += 256) {
+  float* po = partials + (int64_t)blockIdx.x * C;
+  if ((C & 7) == 0 && (ld & 7) == 0) {
+    // blockIdx.y selects a 2048-column chunk; inside it 8 columns per thread
+    const int c0 = blockIdx.y * 2048;
+    const int cw = C - c0 < 2048 ? C - c0 : 2048;
+    const int ncg = cw >> 3;
+    const int rpi = 256 / ncg;
+    const int r = threadIdx.x / ncg, cg = threadIdx.x - r * ncg;
+    float s[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] = 0.f;
+    if (r < rpi) {
+      for (int64_t row = r0 + r; row < r1; row += rpi) {
+        float v[8];
+        load8<T>(x, row * ld + c0 + cg * 8, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] += v[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[threadIdx.x * 8 + k] = s[k];
+    __syncthreads();
+    for (int t = threadIdx.x; t < cw; t += 256) {
+      const int g = t >> 3, k = t & 7;
+      float a = 0.f;
+      for (int rr = 0; rr < rpi; ++rr) a += red[(rr * ncg + g) * 8 + k];
+      po[c0 + t] = a;
+    }
+    return;
+  }
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (c < C) {
     float s = 0.f;
     for (int64_t r = r0; r < r1; ++r) s += ldg<T>(x, r * ld + c);
-    partials[(int64_t)blockIdx.x * C + c] = s;
+    po[c] = s;
   }
 }
 
@@ -369,7 +403,7 @@ extern "C" int adn_attn_bwd(const AdnAttnDesc* d, void* stream) {
 extern "C" int64_t adn_channel_sum_workspace_bytes(int64_t rows, int32_t C) {
   if (rows <= 0 || C <= 0) return -1;
   int64_t P = adn_cdiv(rows, 256);
-  if (P > 512) P = 512;
+  if (P > 1024) P = 1024;
   return P * C * 4;
 }
 
@@ -382,8 +416,10 @@ extern "C" int adn_channel_sum(const void* x, int64_t rows, int32_t C, int32_t l
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int P = (int)(need / (4 * (int64_t)C));
   float* part = reinterpret_cast<float*>(workspace);
-  if (dtype == ADN_BF16) hipLaunchKernelGGL((channel_sum_partial<uint16_t>), dim3(P), dim3(256), 0, st, x, rows, C, ld, part);
-  else hipLaunchKernelGGL((channel_sum_partial<float>), dim3(P), dim3(256), 0, st, x, rows, C, ld, part);
+  const bool vec = (C & 7) == 0 && (ld & 7) == 0;
+  const dim3 grid(P, (unsigned)adn_cdiv(C, vec ? 2048 : 256));
+  if (dtype == ADN_BF16) hipLaunchKernelGGL((channel_sum_partial<uint16_t>), grid, dim3(256), 0, st, x, rows, C, ld, part);
+  else hipLaunchKernelGGL((channel_sum_partial<float>), grid, dim3(256), 0, st, x, rows, C, ld, part);
   ADN_CHECK_LAUNCH();
   hipLaunchKernelGGL(channel_sum_final, dim3((unsigned)adn_cdiv(C, 4)), dim3(256), 0, st, part, P, C, out);
   ADN_CHECK_LAUNCH();
