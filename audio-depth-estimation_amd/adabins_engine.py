@@ -365,6 +365,23 @@ class AdaBinsTrainer:
         self.exp_avg_sq = torch.zeros_like(eng.flat_p)
         self._ready = True
 
+    def state_dict(self):
+        """Optimizer state (flat Adam moments + step counter) for the checkpoint's 'optimizer_state_dict' entry."""
+        if not self._ready:
+            return {'kind': self.opt_kind, 'lr': self.lr, 'step': 0}
+        return {'kind': self.opt_kind, 'lr': self.lr, 'betas': self.betas, 'eps': self.eps,
+                'weight_decay': self.weight_decay, 'step': int(self.state[0].item()),
+                'exp_avg': self.exp_avg.detach().cpu(), 'exp_avg_sq': self.exp_avg_sq.detach().cpu()}
+
+    def load_state_dict(self, sd, device):
+        if not self.engine._bound():
+            self.engine.bind_parameters()
+        self._setup(device)
+        if 'exp_avg' in sd:
+            self.exp_avg.copy_(sd['exp_avg'])
+            self.exp_avg_sq.copy_(sd['exp_avg_sq'])
+            self.state[0] = float(sd['step'])
+
     def step(self, audio, rgb, gt):
         """audio [B,2,H,W], rgb [B,3,H,W] or None, gt [B,1,H,W] -> (total loss 0-dim device tensor, terms f32[8])."""
         eng = self.engine

@@ -163,3 +163,33 @@ def test_depth_target_preparation(dt, norm):
     got = GpuDepthTarget(S, maxd, depth_norm=norm)(torch.from_numpy(src).to('cuda'))
     assert got.shape == (B, 1, S, S)
     np.testing.assert_array_equal(got[:, 0].cpu().numpy(), np.stack(want))
+
+
+@pytest.mark.parametrize('which', ['rgb', 'binaural', 'adabins'])
+def test_dc_trainer_entry_points_synthetic(which, tmp_path, monkeypatch):
+    """train_rgb_depth / train_binaural_attention / train_adabins_distillation counterparts: two epochs on synthetic
+    items, checkpoint layout of the reference scripts, resume from a checkpoint."""
+    import glob
+    from audio_depth_estimation_amd import train_dc
+    monkeypatch.chdir(tmp_path)
+    common = ['--synthetic', '8', '--batch_size', '4', '--nb_epochs', '2', '--experiment_name', 'smoke']
+    if which == 'rgb':
+        model = train_dc.main_rgb(common + ['--save_frequency', '1'])
+        root, pat = 'checkpoints', 'epoch_0002.pth'
+    elif which == 'binaural':
+        model = train_dc.main_binaural(common + ['--save_frequency', '1', '--criterion', 'Combined'])
+        root, pat = 'checkpoints', 'epoch_0002.pth'
+    else:
+        model = train_dc.main_adabins(common + ['--use_adaptive_loss'])
+        root, pat = 'results', 'best_model.pth'
+    files = sorted(os.path.basename(f) for f in glob.glob(os.path.join(root, 'smoke', '*.pth')))
+    assert pat in files and 'best_model.pth' in files, files
+    ck = torch.load(os.path.join(root, 'smoke', pat), map_location='cpu')
+    assert {'epoch', 'model_state_dict', 'optimizer_state_dict'} <= set(ck)
+    assert set(ck['model_state_dict']) == set(model.state_dict())
+    assert all(torch.isfinite(v).all() for v in ck['model_state_dict'].values() if v.is_floating_point())
+    assert ck['optimizer_state_dict']['step'] == 2 * ck['epoch']             # 8 items / batch 4 = 2 steps per epoch
+    if which == 'rgb':                                                         # resume: continues at epoch 3
+        train_dc.main_rgb(common[:4] + ['--nb_epochs', '3', '--experiment_name', 'smoke', '--save_frequency', '1',
+                                        '--checkpoints', '2'])
+        assert os.path.exists(os.path.join('checkpoints', 'smoke', 'epoch_0003.pth'))
