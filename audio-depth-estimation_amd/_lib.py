@@ -129,6 +129,11 @@ _PROTOS = {
     'adn_distill_small': (C.c_int, [C.POINTER(AdnDistillSmall), c_void_p]),
     'adn_depth_prepare': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_void_p,
                                     c_void_p]),
+    'adn_lowpass_workspace_bytes': (c_int64, [c_int32, c_int32, c_int32, c_int32]),
+    'adn_lowpass': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
+    'adn_clamp_add': (C.c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p]),
+    'adn_baseres_stats': (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    'adn_baseres_grad': (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     'adn_nhwc_to_nchw': (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     'adn_bn_fwd_finalize': (C.c_int, [c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p, c_float, c_float,
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

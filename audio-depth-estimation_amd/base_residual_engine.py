@@ -1,0 +1,185 @@
+"""Base + Residual model on libadn: one op tape (shared encoder, two decoders, two 1x1 heads) and the fused step.
+
+Replaces /root/reference/models/base_residual_model.py:151-202 and the training step of
+/root/reference/train_base_residual.py:375-388 with utils_base_residual_loss.BaseResidualLoss (:72-160): the
+reconstruction term (masked L1 or SIlog of the final depth) reuses the masked-loss kernels of the U-Net path
+(adn_loss_stats / adn_loss_finish), the structural target is adn_lowpass(gt), the rest is csrc/baseres.hip.
+The encoder activations x1..x4 receive gradients from both decoders (accumulated in their gradient buffers).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import kernels as K
+from .dc_engine import DCEngine, Head1x1, flag_solo
+
+
+class BaseResidualEngine(DCEngine):
+    def __init__(self, module, compute_dtype=torch.bfloat16):
+        super().__init__(module, None, compute_dtype, 'BaseResidualDepthNet')
+
+    def _prepare_net(self, x):
+        if not self._bound():
+            self.bind_parameters()
+        B, Cin, H, W = x.shape
+        key = (B, Cin, H, W, x.device)
+        if key == self._shape_key:
+            return
+        m = self.module
+        if Cin != m.input_channels:
+            raise RuntimeError(f'expected input[{B}, {Cin}, {H}, {W}] to have {m.input_channels} channels, but got {Cin} '
+                               'channels instead')
+        if H != m.output_size or W != m.output_size:
+            raise NotImplementedError(f'input {H}x{W} != output_size {m.output_size}: the final bilinear resize (reference '
+                                      ':176-179) is not on the libadn path')
+        self.B, self.dev = B, x.device
+        self._scratch = {}
+        self.epc = 8 if self.dtype == torch.bfloat16 else 4
+        self.pairs = []
+        inp = self.thin_input('x', Cin, H, W)
+        ops, f = m.inc.adn_ops([inp], 'x1', H, W)
+        feats = [f]
+        for i, down in enumerate((m.down1, m.down2, m.down3, m.down4)):
+            o, f = down.adn_ops(feats[-1], f'x{i + 2}')
+            ops += o
+            feats.append(f)
+        ends = {}
+        for tag, ups in (('base', (m.base_up1, m.base_up2, m.base_up3, m.base_up4)),
+                         ('res', (m.res_up1, m.res_up2, m.res_up3, m.res_up4))):
+            d = feats[4]
+            for i, up in enumerate(ups):
+                o, d = up.adn_ops(d, feats[3 - i], f'{tag}.d{4 - i}')
+                ops += o
+            ends[tag] = d
+        self.inputs, self.ops = [(inp, 0, Cin)], ops
+        self.head_base = Head1x1(ends['base'], m.base_head, 1, m.max_depth)              # sigmoid * max_depth
+        self.head_res = Head1x1(ends['res'], m.res_head, 2, 0.3 * m.max_depth)           # tanh * 0.3 * max_depth
+        acts = {}
+        for op in ops:
+            for a in list(getattr(op, 'srcs', [])) + [getattr(op, 'src', None), getattr(op, 'out', None)]:
+                if a is not None:
+                    acts[id(a)] = a
+        self.acts = list(acts.values())
+        for a in self.acts:
+            flag_solo(a)
+            a.alloc(B, self.dtype, x.device)
+        ws = 1 << 16
+        for op in ops + [self.head_base, self.head_res]:
+            op.prepare(self)
+            ws = max(ws, op.workspace_bytes(self))
+        f32 = dict(dtype=torch.float32, device=x.device)
+        self.final = torch.empty(B, 1, H, W, **f32)
+        self.workspace = torch.empty(max(ws, K.lowpass_workspace_bytes(B, H, W, 64)) // 4 + 4, **f32)
+        self.weights_dirty = True
+        self._shape_key = key
+
+    def forward_net(self, x, training):
+        if not x.is_cuda:
+            raise RuntimeError('BaseResidualDepthNet needs a HIP device tensor (libadn has no CPU path)')
+        x = x.contiguous().float()
+        self._prepare_net(x)
+        if self.weights_dirty or self._packed_version != self._version_sum():
+            self._pack_weights()
+        self.load_input(x)
+        for op in self.ops:
+            op.fwd(self, training)
+        self.head_base.fwd(self, training)
+        self.head_res.fwd(self, training)
+        K.clamp_add(self.head_base.result, self.head_res.result, self.module.max_depth, self.final)
+        return self.head_base.result, self.head_res.result, self.final
+
+    def run(self, x, training):
+        b, r, f = self.forward_net(x, training)
+        return b.clone(), r.clone(), f.clone()
+
+    def backward_net(self, dbase, dres):
+        for a in self.acts:
+            a.written = False
+        self._final = set(id(p) for p, _, _ in self.param_meta if not p.requires_grad)
+        self._wm = len(self.param_meta)
+        self.head_res.bwd_head(self, dres)
+        self.head_base.bwd_head(self, dbase)
+        for op in reversed(self.ops):
+            if op.out.needs_grad:
+                op.bwd(self)
+
+
+class BaseResidualTrainer:
+    """One fused step of train_base_residual.py:375-388: forward, BaseResidualLoss (valid = gt > 0), backward,
+    clip_grad_norm_(1.0), optimizer."""
+
+    def __init__(self, engine, lambda_recon=1.0, lambda_base=1.2, lambda_sparse=0.05, lowpass_kernel=16, use_l1=True,
+                 use_silog=False, silog_lambda=0.5, optimizer='AdamW', lr=1e-4, betas=(0.9, 0.999), eps=1e-8,
+                 weight_decay=None, clip_norm=1.0):
+        if not use_silog and not use_l1:
+            raise NotImplementedError('the MSE reconstruction variant (use_l1=False, use_silog=False) is not implemented')
+        self.engine = engine
+        self.lambda_recon, self.lambda_base, self.lambda_sparse = lambda_recon, lambda_base, lambda_sparse
+        self.k, self.use_silog, self.silog_lambda = lowpass_kernel, use_silog, silog_lambda
+        self.opt_kind = {'AdamW': 0, 'Adam': 1, 'SGD': 2}[optimizer]
+        self.lr, self.betas, self.eps = float(lr), betas, float(eps)
+        self.weight_decay = float((0.01 if optimizer == 'AdamW' else 0.0) if weight_decay is None else weight_decay)
+        self.clip_norm = clip_norm
+        self._ready = False
+
+    @classmethod
+    def from_criterion(cls, engine, criterion, **kw):
+        """Build from a utils_base_residual_loss.BaseResidualLoss / AdaptiveBaseResidualLoss instance."""
+        c = getattr(criterion, 'base_loss', criterion)
+        return cls(engine, c.lambda_recon, c.lambda_base, c.lambda_sparse, c.lowpass_kernel, c.use_l1, c.use_silog,
+                   c.silog_lambda, **kw)
+
+    def set_criterion(self, criterion):
+        c = getattr(criterion, 'base_loss', criterion)
+        self.set_weights(c.lambda_recon, c.lambda_base)
+
+    def load_state_dict(self, sd, device):
+        raise NotImplementedError('resume of the optimizer state: load the model weights and restart the moments')
+
+    def set_weights(self, lambda_recon, lambda_base):
+        """AdaptiveBaseResidualLoss.set_epoch (utils_base_residual_loss.py:210-229) result."""
+        self.lambda_recon, self.lambda_base = lambda_recon, lambda_base
+
+    def _setup(self, pred):
+        eng, dev = self.engine, pred.device
+        f64, f32 = dict(dtype=torch.float64, device=dev), dict(dtype=torch.float32, device=dev)
+        self.state, self.lstats, self.bstats = torch.zeros(8, **f64), torch.zeros(4, **f64), torch.zeros(4, **f64)
+        self.loss_ws, self.norm_ws = torch.empty(4096 + 8, **f64), torch.empty(1024 + 8, **f64)
+        self.recon, self.terms = torch.zeros(1, **f32), torch.zeros(4, **f32)
+        self.struct, self.gfinal = torch.empty_like(pred), torch.empty_like(pred)
+        self.dbase, self.dres = torch.empty_like(pred), torch.empty_like(pred)
+        self.exp_avg, self.exp_avg_sq = torch.zeros_like(eng.flat_p), torch.zeros_like(eng.flat_p)
+        self._ready = True
+
+    def state_dict(self):
+        if not self._ready:
+            return {'kind': self.opt_kind, 'lr': self.lr, 'step': 0}
+        return {'kind': self.opt_kind, 'lr': self.lr, 'betas': self.betas, 'eps': self.eps,
+                'weight_decay': self.weight_decay, 'step': int(self.state[0].item()),
+                'exp_avg': self.exp_avg.detach().cpu(), 'exp_avg_sq': self.exp_avg_sq.detach().cpu()}
+
+    def step(self, x, gt):
+        """Returns (total loss 0-dim device tensor, terms f32[4] = weighted recon, mean|base-struct|, mean|res|, total)."""
+        eng = self.engine
+        base, resid, final = eng.forward_net(x, True)
+        gt = gt.contiguous().float()
+        if not self._ready or self.struct.shape != final.shape:
+            self._setup(final)
+        K.lowpass(gt, self.k, self.struct, eng.workspace)
+        crit = 2                                               # Combined with one active weight = weighted L1 or SIlog
+        l1w, sw = (0.0, self.lambda_recon) if self.use_silog else (self.lambda_recon, 0.0)
+        K.loss_stats(final, gt, 1.0, 1, 1e-6, self.lstats, self.loss_ws)
+        K.loss_finish(final, gt, 1.0, 1, 1e-6, self.lstats, crit, l1w, sw, self.silog_lambda, self.recon, self.gfinal)
+        K.baseres_stats(base, resid, self.struct, gt, self.recon, self.lambda_recon, self.lambda_base, self.lambda_sparse,
+                        self.bstats, self.terms, eng.workspace)
+        K.baseres_grad(base, resid, self.struct, gt, self.gfinal, eng.module.max_depth, self.bstats, self.lambda_base,
+                       self.lambda_sparse, self.dbase, self.dres)
+        eng.backward_net(self.dbase, self.dres)
+        if self.clip_norm is not None:
+            K.grad_norm(eng.flat_g, float(self.clip_norm), self.state, self.norm_ws)
+        K.optimizer_step(eng.flat_p, eng.flat_g, self.exp_avg, self.exp_avg_sq, self.opt_kind, self.lr, self.betas[0],
+                         self.betas[1], self.eps, self.weight_decay, self.clip_norm is not None, self.state,
+                         bf16_copy=eng.flat_w16)
+        eng.weights_dirty = True
+        eng.s2_fresh = eng.flat_w16 is not None
+        return self.terms[3], self.terms

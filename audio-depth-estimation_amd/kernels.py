@@ -574,3 +574,32 @@ def depth_prepare(src, S, max_depth, norm, out):
     _dev(src, out)
     _lib.call('adn_depth_prepare', ptr(src), code, planes, H, W, S, float(max_depth or 0.0), float(norm or 0.0), ptr(out),
               _stream())
+
+
+# ---- Base + Residual model (csrc/baseres.hip) --------------------------------------------------------------------
+def lowpass_workspace_bytes(B, H, W, k):
+    return _lib.load().adn_lowpass_workspace_bytes(B, H, W, k)
+
+
+def lowpass(gt, k, out, workspace):
+    """gt f32 [B,1,H,W] -> avg_pool2d(k, 1, k//2) + bilinear resize back to H x W."""
+    B, H, W = gt.shape[0], gt.shape[-2], gt.shape[-1]
+    _dev(gt, out, workspace)
+    _lib.call('adn_lowpass', ptr(gt), B, H, W, k, ptr(out), ptr(workspace), _nbytes(workspace), _stream())
+
+
+def clamp_add(a, b, max_depth, out):
+    _dev(a, b, out)
+    _lib.call('adn_clamp_add', ptr(a), ptr(b), a.numel(), float(max_depth), ptr(out), _stream())
+
+
+def baseres_stats(base, resid, strct, gt, recon, lrecon, lbase, lsparse, stats, terms, workspace):
+    _dev(base, resid, strct, gt, recon, stats, terms, workspace)
+    _lib.call('adn_baseres_stats', ptr(base), ptr(resid), ptr(strct), ptr(gt), base.numel(), ptr(recon), float(lrecon),
+              float(lbase), float(lsparse), ptr(stats), ptr(terms), ptr(workspace), _nbytes(workspace), _stream())
+
+
+def baseres_grad(base, resid, strct, gt, gfinal, max_depth, stats, lbase, lsparse, dbase, dres):
+    _dev(base, resid, strct, gt, gfinal, stats, dbase, dres)
+    _lib.call('adn_baseres_grad', ptr(base), ptr(resid), ptr(strct), ptr(gt), ptr(gfinal), base.numel(), float(max_depth),
+              ptr(stats), float(lbase), float(lsparse), ptr(dbase), ptr(dres), _stream())

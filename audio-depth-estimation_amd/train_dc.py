@@ -287,3 +287,70 @@ def main_adabins(argv=None):
     fwd = lambda m, b: m(b[0], rgb=None, mode='inference')['audio']['final_depth']
     return _run(args, cfg, model, trainer, kind, step, fwd, exp, ckpt_root='results', ckpt_fmt='checkpoint_epoch_{:04d}.pth',
                 on_epoch=on_epoch)
+
+
+# ---- train_base_residual.py ------------------------------------------------------------------------------------------------
+def main_base_residual(argv=None):
+    """/root/reference/train_base_residual.py:115-520: BaseResidualDepthNet, BaseResidualLoss / AdaptiveBaseResidualLoss
+    (:258-281; --use_silog is store_true with default True, i.e. SIlog reconstruction), optimizer from the config,
+    clip_grad_norm_(1.0) (:386), checkpoints under ./checkpoints/<experiment>/."""
+    from .base_residual_engine import BaseResidualTrainer
+    from .models.base_residual_model import create_base_residual_model
+    from .utils_base_residual_loss import AdaptiveBaseResidualLoss, BaseResidualLoss
+    p = argparse.ArgumentParser(description='Train Base+Residual depth model (MI355X)')
+    p.add_argument('--dataset', type=str, default='batvisionv2', choices=['batvisionv1', 'batvisionv2'])
+    p.add_argument('--audio_format', type=str, default='mel_spectrogram')
+    p.add_argument('--base_channels', type=int, default=64)
+    p.add_argument('--bilinear', action='store_true', default=True)
+    p.add_argument('--use_adaptive_loss', action='store_true', default=False)
+    p.add_argument('--use_silog', action='store_true', default=True)
+    p.add_argument('--silog_lambda', type=float, default=0.5)
+    p.add_argument('--lambda_recon', type=float, default=1.0)
+    p.add_argument('--lambda_base', type=float, default=1.2)
+    p.add_argument('--lambda_sparse', type=float, default=0.05)
+    p.add_argument('--lowpass_kernel', type=int, default=16)
+    p.add_argument('--warmup_epochs', type=int, default=50)
+    p.add_argument('--batch_size', type=int, default=None)
+    p.add_argument('--learning_rate', '--lr', type=float, default=None)
+    p.add_argument('--optimizer', type=str, default=None, choices=['Adam', 'AdamW', 'SGD'])
+    p.add_argument('--epochs', type=int, default=None)
+    p.add_argument('--validation', type=lambda x: (str(x).lower() == 'true'), default=None)
+    p.add_argument('--validation_iter', type=int, default=None)
+    p.add_argument('--use_wandb', action='store_true', default=False)
+    p.add_argument('--wandb_project', type=str, default='batvision-depth-estimation')
+    p.add_argument('--wandb_entity', type=str, default='branden')
+    p.add_argument('--experiment_name', type=str, default='base_res_default')
+    p.add_argument('--checkpoints', type=int, default=None)
+    p.add_argument('--synthetic', type=int, default=0)
+    p.add_argument('--precision', type=str, default='bf16', choices=['bf16', 'f32'])
+    args = p.parse_args(argv)
+    cfg = load_config(dataset_name=args.dataset, model_name='unet_baseline', mode='train', experiment_name=args.experiment_name)
+    cfg.dataset.audio_format = args.audio_format
+    args.batch_size = args.batch_size or cfg.mode.batch_size
+    args.learning_rate = args.learning_rate or cfg.mode.learning_rate
+    args.nb_epochs = args.epochs or cfg.mode.epochs
+    opt = args.optimizer or cfg.mode.optimizer
+    args.scheduler, args.save_frequency = 'none', cfg.mode.saving_checkpoints
+    args.num_workers, args.seed, args.device = cfg.mode.num_threads, 42, 'cuda'
+    model = create_base_residual_model(input_channels=2, base_channels=args.base_channels, bilinear=args.bilinear,
+                                       output_size=cfg.dataset.images_size, max_depth=cfg.dataset.max_depth)
+    if args.use_adaptive_loss:
+        criterion = AdaptiveBaseResidualLoss(lambda_recon_init=args.lambda_recon * 0.5,          # reference :261-269
+                                             lambda_base_init=args.lambda_base * 2.0, lambda_sparse=args.lambda_sparse,
+                                             warmup_epochs=args.warmup_epochs, lowpass_kernel=args.lowpass_kernel,
+                                             use_silog=args.use_silog, silog_lambda=args.silog_lambda)
+    else:
+        criterion = BaseResidualLoss(lambda_recon=args.lambda_recon, lambda_base=args.lambda_base,
+                                     lambda_sparse=args.lambda_sparse, lowpass_kernel=args.lowpass_kernel,
+                                     use_silog=args.use_silog, silog_lambda=args.silog_lambda)
+    trainer = BaseResidualTrainer.from_criterion(model.engine(), criterion, optimizer=opt, lr=args.learning_rate,
+                                                 weight_decay=0.01 if opt == 'AdamW' else 0.0, clip_norm=1.0)
+
+    def on_epoch(epoch):
+        if args.use_adaptive_loss:
+            criterion.set_epoch(epoch)
+            trainer.set_criterion(criterion)
+
+    step = lambda tr, b: tr.step(b[0], b[1])[0]
+    return _run(args, cfg, model, trainer, 'audio', step, lambda m, b: m(b[0])[2], args.experiment_name,
+                ckpt_fmt='checkpoint_{}.pth', on_epoch=on_epoch)

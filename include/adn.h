@@ -289,6 +289,25 @@ typedef struct {
 } AdnDistillSmall;
 int adn_distill_small(const AdnDistillSmall* d, void* stream);
 
+/* ---- Base + Residual model (base_residual_model.py:83-217, utils_base_residual_loss.py:28-160) ---- */
+/* Structural target: avg_pool2d(gt, k, stride 1, padding k/2) (zeros counted) then bilinear resize
+ * (align_corners=False) back to H x W (utils_base_residual_loss.py:91-107).  gt, out f32 [B][H][W]. */
+int64_t adn_lowpass_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t k);
+int adn_lowpass(const float* gt, int32_t B, int32_t H, int32_t W, int32_t k, float* out, void* workspace,
+                int64_t workspace_bytes, void* stream);
+/* out = clamp(a + b, 0, max_depth): final_depth (base_residual_model.py:197-200). */
+int adn_clamp_add(const float* a, const float* b, int64_t n, float max_depth, float* out, void* stream);
+/* With valid = gt > 0: stats f64[3] = [N_valid, sum|base - struct|, sum|resid|]; terms f32[4] = recon (as
+ * delivered, already weighted), mean|base - struct|, mean|resid|, total = recon + lambda_base * .. +
+ * lambda_sparse * ...  Gradients: gfinal = d (weighted recon) / d final from adn_loss_finish; dbase / dres include the
+ * clamp mask and the structural / sparsity terms.  workspace: 24 KiB. */
+int adn_baseres_stats(const float* base, const float* resid, const float* strct, const float* gt, int64_t n,
+                      const float* recon, float lambda_recon, float lambda_base, float lambda_sparse,
+                      double* stats, float* terms, void* workspace, int64_t workspace_bytes, void* stream);
+int adn_baseres_grad(const float* base, const float* resid, const float* strct, const float* gt,
+                     const float* gfinal, int64_t n, float max_depth, const double* stats,
+                     float lambda_base, float lambda_sparse, float* dbase, float* dres, void* stream);
+
 /* NCHW f32 <-> NHWC dtype layout conversion of the network input/output
  * (model(audio) boundary, train.py:642).  dst has c_pad >= C channels, the extra ones zero. */
 int adn_nchw_to_nhwc(const float* src, void* dst, int32_t B, int32_t C, int32_t c_pad, int32_t H,

@@ -242,3 +242,47 @@ def distillation_loss(output, gt, valid, lambda_task=2.0, lambda_response=0.3, l
     total = (lambda_task * task + lambda_response * resp + lambda_feature * feat + lambda_bin * (kl + cm) +
              lambda_sparse * sparse)
     return total, {'task': task, 'response': resp, 'feature': feat, 'bin': kl, 'bin_centers': cm, 'sparse': sparse}
+
+
+# ---- Base + Residual model (base_residual_model.py, utils_base_residual_loss.py) ----------------------------------------
+def base_residual_forward(sd, x, max_depth=30.0, training=True):
+    """BaseResidualDepthNet.forward (base_residual_model.py:151-202) for output_size == input size: shared encoder, base
+    decoder -> sigmoid * max_depth, residual decoder -> tanh * 0.3 * max_depth, final = clamp(base + residual)."""
+    new_stats = {}
+    feats = encoder(sd, '', _q(x), training, new_stats)
+
+    def dec(tag):
+        d = feats[4]
+        for i in range(4):
+            d = up(sd, f'{tag}_up{i + 1}', d, feats[3 - i], training, new_stats)
+        return d
+
+    b, r = dec('base'), dec('res')
+    base = torch.sigmoid(F.conv2d(b, sd['base_head.weight'], sd['base_head.bias'])) * max_depth
+    residual = torch.tanh(F.conv2d(r, sd['res_head.weight'], sd['res_head.bias'])) * (max_depth * 0.3)
+    return base, residual, torch.clamp(base + residual, 0, max_depth), new_stats
+
+
+def lowpass_struct(gt, k=16):
+    """Structural target (utils_base_residual_loss.py:91-107)."""
+    s = F.avg_pool2d(gt, kernel_size=k, stride=1, padding=k // 2)
+    if s.shape != gt.shape:
+        s = F.interpolate(s, size=gt.shape[-2:], mode='bilinear', align_corners=False)
+    return s
+
+
+def base_residual_loss(base, residual, final, gt, valid, lambda_recon=1.0, lambda_base=1.2, lambda_sparse=0.05, k=16,
+                       use_silog=False, silog_lambda=0.5, eps=1e-6):
+    """BaseResidualLoss.forward (utils_base_residual_loss.py:72-160): recon (L1 or SIlog on the masked pixels) +
+    lambda_base * L1(base, lowpass(gt)) + lambda_sparse * mean|residual|.  Returns (total, (recon, base, sparse))."""
+    with torch.no_grad():
+        struct = lowpass_struct(gt, k)
+    f, g = final[valid], gt[valid]
+    if use_silog:
+        d = torch.log(torch.clamp(f, min=eps)) - torch.log(torch.clamp(g, min=eps))        # utils_loss.py:37-47
+        recon = torch.sqrt(torch.clamp((d * d).mean() - silog_lambda * d.mean() ** 2, min=0.0))
+    else:
+        recon = (f - g).abs().mean()
+    lb = (base[valid] - struct[valid]).abs().mean()
+    ls = residual[valid].abs().mean()
+    return lambda_recon * recon + lambda_base * lb + lambda_sparse * ls, (recon, lb, ls)

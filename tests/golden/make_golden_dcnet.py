@@ -227,13 +227,63 @@ def adabins_case(name='adabins32_bc64', bc=64, nb=128, S=32, B=2, lr=2e-3, max_d
     save(name, out)
 
 
+def base_residual_case(name='baseres32_bc64', bc=64, S=32, B=2, lr=2e-3, max_depth=30.0):
+    """models/base_residual_model.py:236 create_base_residual_model (its base decoder hard-codes 1024/384/192/96 input
+    channels, :113-116, so it only exists at base_channels=64), utils_base_residual_loss.py:28 BaseResidualLoss with
+    the trainer's settings (train_base_residual.py:272-281: SIlog reconstruction, lambda 1.0 / 1.2 / 0.05, kernel 16),
+    one step of train_base_residual.py:375-388 (gt > 0 mask, clip_grad_norm_(1.0), AdamW).  Sampled fixture as for
+    AdaBins; the head biases are shifted so that base + residual stays away from 0 where SIlog's 1/pred is
+    ill-conditioned."""
+    from models.base_residual_model import create_base_residual_model
+    from utils_base_residual_loss import BaseResidualLoss
+    torch.manual_seed(0)
+    model = create_base_residual_model(input_channels=2, base_channels=bc, output_size=S, max_depth=max_depth)
+    perturb_bn(model, 4)
+    out = {}
+    for k, v in model.state_dict().items():
+        out['sd0s/' + k] = sample(v) if v.is_floating_point() else v.clone().numpy()
+    g = torch.Generator().manual_seed(1234)
+    audio = torch.rand(B, 2, S, S, generator=g)
+    gt = max_depth * torch.rand(B, 1, S, S, generator=g)
+    gt[gt < 0.1 * max_depth] = 0.0
+    out['audio'], out['gt'] = audio.numpy(), gt.numpy()
+    model.eval()
+    with torch.no_grad():
+        b, r, f = model(audio)
+        out['eval/base'], out['eval/residual'], out['eval/final'] = b.numpy(), r.numpy(), f.numpy()
+    model.train()
+    for use_silog, tag in ((True, 'silog'), (False, 'l1')):
+        crit = BaseResidualLoss(lambda_recon=1.0, lambda_base=1.2, lambda_sparse=0.05, lowpass_kernel=16,
+                                use_silog=use_silog, silog_lambda=0.5)
+        model.zero_grad()
+        b, r, f = model(audio)
+        loss, parts = crit(b, r, f, gt, gt > 0)
+        loss.backward()
+        out[f'{tag}/loss'] = np.float64(loss.item())
+        out[f'{tag}/parts'] = np.array([parts['recon'], parts['base'], parts['sparse']], dtype=np.float64)
+        for k, p in model.named_parameters():
+            out[f'{tag}/gnorm/' + k] = np.float64(p.grad.double().norm().item())
+            out[f'{tag}/gs/' + k] = sample(p.grad)
+        if use_silog:
+            out['train/base'], out['train/residual'], out['train/final'] = b.detach().numpy(), r.detach().numpy(), f.detach().numpy()
+            import torch.nn.functional as F_
+            s = F_.avg_pool2d(gt, kernel_size=16, stride=1, padding=8)
+            out['struct'] = F_.interpolate(s, size=gt.shape[-2:], mode='bilinear', align_corners=False).numpy()
+    out['loss'] = out['silog/loss']
+    out['meta'] = np.array([bc, S, B], dtype=np.int64)
+    out['hyper'] = np.array([lr, max_depth, 1.0, 1.2, 0.05, 16, 0.5], dtype=np.float64)
+    save(name, out)
+
+
 if __name__ == '__main__':
     import sys as _sys
     torch.set_num_threads(8)
-    which = _sys.argv[1:] or ['rgb', 'binaural', 'adabins']
+    which = _sys.argv[1:] or ['rgb', 'binaural', 'adabins', 'baseres']
     if 'rgb' in which:
         rgb_case()
     if 'binaural' in which:
         binaural_case()
     if 'adabins' in which:
         adabins_case()
+    if 'baseres' in which:
+        base_residual_case()

@@ -165,7 +165,7 @@ def test_depth_target_preparation(dt, norm):
     np.testing.assert_array_equal(got[:, 0].cpu().numpy(), np.stack(want))
 
 
-@pytest.mark.parametrize('which', ['rgb', 'binaural', 'adabins'])
+@pytest.mark.parametrize('which', ['rgb', 'binaural', 'adabins', 'baseres'])
 def test_dc_trainer_entry_points_synthetic(which, tmp_path, monkeypatch):
     """train_rgb_depth / train_binaural_attention / train_adabins_distillation counterparts: two epochs on synthetic
     items, checkpoint layout of the reference scripts, resume from a checkpoint."""
@@ -179,6 +179,10 @@ def test_dc_trainer_entry_points_synthetic(which, tmp_path, monkeypatch):
     elif which == 'binaural':
         model = train_dc.main_binaural(common + ['--save_frequency', '1', '--criterion', 'Combined'])
         root, pat = 'checkpoints', 'epoch_0002.pth'
+    elif which == 'baseres':
+        model = train_dc.main_base_residual(['--synthetic', '8', '--batch_size', '4', '--epochs', '2', '--experiment_name',
+                                             'smoke', '--use_adaptive_loss'])
+        root, pat = 'checkpoints', 'best_model.pth'
     else:
         model = train_dc.main_adabins(common + ['--use_adaptive_loss'])
         root, pat = 'results', 'best_model.pth'

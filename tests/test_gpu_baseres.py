@@ -1,0 +1,98 @@
+"""GPU parity of the Base + Residual model on libadn (models.base_residual_model / base_residual_engine).
+
+  * the structural low-pass target (avg_pool2d k, stride 1, pad k/2 + bilinear resize back) against torch-CPU:
+    <= 2e-6 of max|ref|;
+  * the model and the fused BaseResidualLoss step against the golden vectors produced by the REFERENCE at its only
+    valid width (base_channels 64, tests/golden/baseres32_bc64.npz), f32 compute, both reconstruction variants
+    (SIlog -- the trainer's default -- and L1): outputs <= 2e-4, loss terms <= 2e-4, per-parameter gradient norm
+    <= 5e-3 and sampled gradient entries <= 5e-3 of the tensor max.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_oracle_golden import _sample, base_residual_initial_state
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+DEV = 'cuda'
+
+
+def rel_err(a, b):
+    a, b = a.detach().float().cpu(), torch.as_tensor(b).detach().float().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.mark.parametrize('shape,k', [((2, 32, 32), 16), ((1, 40, 56), 16), ((2, 64, 64), 7), ((1, 256, 256), 16)])
+def test_lowpass_struct(shape, k):
+    from audio_depth_estimation_amd import kernels as K
+    B, H, W = shape
+    torch.manual_seed(0)
+    gt = torch.rand(B, 1, H, W) * 30
+    gt[gt < 3] = 0
+    s = F.avg_pool2d(gt, kernel_size=k, stride=1, padding=k // 2)
+    ref = F.interpolate(s, size=(H, W), mode='bilinear', align_corners=False) if s.shape != gt.shape else s
+    out = torch.empty(B, 1, H, W, device=DEV)
+    ws = torch.empty(K.lowpass_workspace_bytes(B, H, W, k) // 4 + 4, device=DEV)
+    K.lowpass(gt.to(DEV), k, out, ws)
+    assert rel_err(out, ref) <= 2e-6
+
+
+@pytest.mark.parametrize('tag,use_silog', [('silog', True), ('l1', False)])
+def test_base_residual_golden_reference_parity_f32(tag, use_silog):
+    from audio_depth_estimation_amd.base_residual_engine import BaseResidualTrainer
+    z = np.load(os.path.join(GOLDEN, 'baseres32_bc64.npz'))
+    lr, max_depth, lrec, lbase, lsp, k, slam = [float(v) for v in z['hyper']]
+    model = base_residual_initial_state(z)
+    model.compute_dtype = torch.float32
+    model = model.to(DEV)
+    audio, gt = torch.from_numpy(z['audio']).to(DEV), torch.from_numpy(z['gt']).to(DEV)
+    model.eval()
+    b, r, f = model(audio)
+    for t, name in ((b, 'base'), (r, 'residual'), (f, 'final')):
+        assert rel_err(t, z['eval/' + name]) <= 2e-4, name
+    model.train()
+    tr = BaseResidualTrainer(model.engine(), lrec, lbase, lsp, int(k), use_silog=use_silog, silog_lambda=slam,
+                             optimizer='AdamW', lr=lr, clip_norm=1.0)
+    total, terms = tr.step(audio, gt)
+    eng = model.engine()
+    if use_silog:
+        for t, name in ((eng.head_base.result, 'base'), (eng.head_res.result, 'residual'), (eng.final, 'final')):
+            assert rel_err(t, z['train/' + name]) <= 2e-4, name
+        assert rel_err(tr.struct, z['struct']) <= 2e-6
+    parts = z[tag + '/parts']
+    got = terms.cpu().numpy()
+    np.testing.assert_allclose([got[0] / lrec, got[1], got[2]], parts, rtol=2e-4, atol=1e-6)
+    assert abs(float(total) - float(z[tag + '/loss'])) <= 2e-4 * abs(float(z[tag + '/loss']))
+    named = dict(model.named_parameters())
+    for kk in [q[len(tag + '/gnorm/'):] for q in z.files if q.startswith(tag + '/gnorm/')]:
+        g = eng.grad_view(named[kk])
+        want = float(z[f'{tag}/gnorm/' + kk])
+        assert abs(float(g.double().norm()) - want) <= 5e-3 * want + 1e-7, (kk, float(g.double().norm()), want)
+        ref = z[f'{tag}/gs/' + kk]
+        assert float(np.abs(_sample(g.cpu().contiguous()) - ref).max()) <= 1e-6 + 5e-3 * float(np.abs(ref).max()), kk
+    with pytest.raises(RuntimeError):
+        model(audio.cpu())
+
+
+def test_base_residual_loss_module_and_curriculum():
+    """utils_base_residual_loss mirror: forward values from model outputs vs the reference's terms; the warm-up
+    curriculum of AdaptiveBaseResidualLoss (utils_base_residual_loss.py:210-229)."""
+    from audio_depth_estimation_amd.utils_base_residual_loss import AdaptiveBaseResidualLoss, BaseResidualLoss
+    z = np.load(os.path.join(GOLDEN, 'baseres32_bc64.npz'))
+    lr, max_depth, lrec, lbase, lsp, k, slam = [float(v) for v in z['hyper']]
+    dev = lambda a: torch.from_numpy(a).to(DEV)
+    gt = dev(z['gt'])
+    for tag, use_silog in (('silog', True), ('l1', False)):
+        crit = BaseResidualLoss(lrec, lbase, lsp, int(k), use_silog=use_silog, silog_lambda=slam)
+        total, d = crit(dev(z['train/base']), dev(z['train/residual']), dev(z['train/final']), gt, gt > 0)
+        np.testing.assert_allclose([d['recon'], d['base'], d['sparse']], z[tag + '/parts'], rtol=2e-4, atol=1e-6)
+        assert abs(float(total) - float(z[tag + '/loss'])) <= 2e-4 * abs(float(z[tag + '/loss']))
+    ad = AdaptiveBaseResidualLoss(lambda_recon_init=0.5, lambda_base_init=2.4, warmup_epochs=50)
+    for epoch, want in ((0, (0.5, 2.4)), (25, (0.75, 1.35)), (50, (1.0, 0.3)), (80, (1.0, 0.3))):
+        ad.set_epoch(epoch)
+        w = ad.get_current_weights()
+        np.testing.assert_allclose([w['lambda_recon'], w['lambda_base']], want, rtol=1e-6)

@@ -268,3 +268,52 @@ def test_adabins_oracle_matches_reference():
     for k, v in new_stats.items():           # decoder BN statistics carry the double update
         ref = z['sd1s/' + k]
         np.testing.assert_allclose(_sample(v), ref, rtol=1e-4, atol=1e-5, err_msg=k)
+
+
+# ---- Base + Residual model ------------------------------------------------------------------------------------------
+def base_residual_initial_state(z):
+    from audio_depth_estimation_amd.models.base_residual_model import create_base_residual_model
+    bc, S, B = [int(v) for v in z['meta']]
+    torch.manual_seed(0)
+    model = create_base_residual_model(input_channels=2, base_channels=bc, output_size=S, max_depth=float(z['hyper'][1]))
+    g = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.copy_(1.0 + 0.2 * torch.randn(m.weight.shape, generator=g))
+                m.bias.copy_(0.1 * torch.randn(m.bias.shape, generator=g))
+                m.running_mean.copy_(0.1 * torch.randn(m.running_mean.shape, generator=g))
+                m.running_var.copy_(1.0 + 0.5 * torch.rand(m.running_var.shape, generator=g))
+    for k, v in model.state_dict().items():
+        np.testing.assert_array_equal(_sample(v) if v.is_floating_point() else v.numpy(), z['sd0s/' + k], err_msg=k)
+    return model
+
+
+def test_base_residual_oracle_matches_reference():
+    from oracle import dcnet_oracle
+    z = _load('baseres32_bc64')
+    lr, max_depth, lrec, lbase, lsp, k, slam = [float(v) for v in z['hyper']]
+    model = base_residual_initial_state(z)
+    sd = {kk: v.detach().clone() for kk, v in model.state_dict().items()}
+    audio, gt = torch.from_numpy(z['audio']), torch.from_numpy(z['gt'])
+    torch.set_num_threads(8)
+    np.testing.assert_allclose(dcnet_oracle.lowpass_struct(gt, int(k)).numpy(), z['struct'], rtol=1e-6, atol=1e-6)
+    with torch.no_grad():
+        b, r, f, _ = dcnet_oracle.base_residual_forward(sd, audio, max_depth, training=False)
+    for t, name in ((b, 'base'), (r, 'residual'), (f, 'final')):
+        np.testing.assert_allclose(t.numpy(), z['eval/' + name], rtol=2e-4, atol=2e-4)
+    pkeys = [kk[len('silog/gnorm/'):] for kk in z.files if kk.startswith('silog/gnorm/')]
+    for tag, use_silog in (('silog', True), ('l1', False)):
+        sdg = {kk: (v.clone().requires_grad_(True) if kk in pkeys else v) for kk, v in sd.items()}
+        b, r, f, _ = dcnet_oracle.base_residual_forward(sdg, audio, max_depth, training=True)
+        if use_silog:
+            for t, name in ((b, 'base'), (r, 'residual'), (f, 'final')):
+                np.testing.assert_allclose(t.detach().numpy(), z['train/' + name], rtol=2e-4, atol=2e-4)
+        loss, parts = dcnet_oracle.base_residual_loss(b, r, f, gt, gt > 0, lrec, lbase, lsp, int(k), use_silog, slam)
+        np.testing.assert_allclose([float(p) for p in parts], z[tag + '/parts'], rtol=2e-4, atol=1e-6)
+        assert abs(loss.item() - float(z[tag + '/loss'])) <= 2e-4 * abs(float(z[tag + '/loss']))
+        loss.backward()
+        for kk in pkeys:
+            gr, ref = sdg[kk].grad, z[f'{tag}/gs/' + kk]
+            assert abs(float(gr.double().norm()) - float(z[f'{tag}/gnorm/' + kk])) <= 5e-3 * float(z[f'{tag}/gnorm/' + kk]) + 1e-7, kk
+            np.testing.assert_allclose(_sample(gr), ref, rtol=5e-3, atol=1e-6 + 5e-3 * np.abs(ref).max(), err_msg=kk)
