@@ -306,21 +306,34 @@ class Head1x1(Op):
         self.zpre = torch.empty(pixels, **f32)
         self.result = torch.empty(eng.B, 1, s.H, s.W, **f32)
         self._ws = K.head1x1_bwd_workspace_bytes(pixels, s.C)
+        self.c_real = getattr(s, 'C_real', s.C)
+        if self.c_real != s.C:                          # zero-padded source: padded weight copy / gradient temporary
+            self.w_p, self.dw_p = torch.zeros(s.C, **f32), torch.empty(s.C, **f32)
 
     def workspace_bytes(self, eng):
         return self._ws
 
-    def fwd(self, eng, training):
+    def _weight(self, eng):
         w = eng._flat_slice(eng.flat_p, self.conv.weight)
-        K.head1x1_fwd(self.src.data, w, self.conv.bias, self.act, self.max_depth, self.zpre, self.result)
+        if self.c_real != self.src.C:
+            K.pack_rows(w, self.c_real, 1, 1, self.w_p[:self.c_real])
+            return self.w_p
+        return w
+
+    def fwd(self, eng, training):
+        K.head1x1_fwd(self.src.data, self._weight(eng), self.conv.bias, self.act, self.max_depth, self.zpre, self.result)
 
     def bwd_head(self, eng, gout):
         s = self.src
         assert not s.written
-        w = eng._flat_slice(eng.flat_p, self.conv.weight)
+        padded = self.c_real != s.C
+        w = self.w_p if padded else eng._flat_slice(eng.flat_p, self.conv.weight)
         db = eng._flat_slice(eng.flat_g, self.conv.bias) if self.conv.bias is not None else None
-        K.head1x1_bwd(gout, self.zpre, s.data, w, self.act, self.max_depth, s.grad,
-                      eng._flat_slice(eng.flat_g, self.conv.weight), db, eng.workspace)
+        dw = eng._flat_slice(eng.flat_g, self.conv.weight)
+        K.head1x1_bwd(gout, self.zpre, s.data, w, self.act, self.max_depth, s.grad, self.dw_p if padded else dw, db,
+                      eng.workspace)
+        if padded:
+            K.pack_rows(self.dw_p[:self.c_real], self.c_real, 1, 1, dw)
         s.written = True
         eng._mark(self.conv.bias)
         eng._ready(self.conv.weight)
@@ -433,16 +446,38 @@ class CrossAttention(Op):
         eng._ready(m.query.weight)
 
 
+def _pad_ok(a):
+    """Every consumer can take extra zero channels at the END of this record: a conv that reads it as its last
+    source, the 1x1 head, or an upsample whose own output qualifies."""
+    for c in a.consumers:
+        if isinstance(c, ConvBNReLU):
+            if c.srcs[-1] is not a:
+                return False
+        elif isinstance(c, Upsample2x):
+            if not _pad_ok(c.out):
+                return False
+        elif not isinstance(c, Head1x1):
+            return False
+    return True
+
+
 def flag_solo(a):
-    """Mark an activation whose only consumer is a single-source conv (the mid tensor of a DoubleConv): the consumer's
-    dgrad epilogue applies its ReLU mask + BN statistics, and -- nobody else looking at it -- its channel count may be
-    zero-padded to a multiple of 64 to reach the MFMA kernels (96 -> 128 in the AdaBins decoder, 32 -> 64 at narrow
-    widths)."""
+    """Per-record decisions taken once the tape is known (records are visited in forward order):
+      * fused_bwd: the only consumer is a single-source conv (the mid tensor of a DoubleConv) -- that conv's dgrad
+        epilogue applies the ReLU mask + BN statistics;
+      * zero padding of the channel count to a multiple of 64 so that narrow layers reach the MFMA kernels (96 -> 128
+        in the AdaBins decoder, 32 / 16 -> 64 in the Base+Residual base decoder and at narrow test widths), allowed
+        when every consumer tolerates trailing zero channels (_pad_ok); an upsample output inherits its source's
+        padding."""
     prod = a.producer
-    solo = (isinstance(prod, ConvBNReLU) and len(a.consumers) == 1 and isinstance(a.consumers[0], ConvBNReLU) and
-            len(a.consumers[0].srcs) == 1)
+    if isinstance(prod, Upsample2x) and hasattr(prod.src, 'C_real') and a.data is None:
+        a.C_real, a.C = prod.src.C_real, prod.src.C
+        return
+    if not isinstance(prod, ConvBNReLU):
+        return
+    solo = len(a.consumers) == 1 and isinstance(a.consumers[0], ConvBNReLU) and len(a.consumers[0].srcs) == 1
     a.fused_bwd = solo and a.needs_grad
-    if solo and a.C % 64 != 0 and a.C >= 32 and a.data is None and not hasattr(a, 'C_real'):
+    if a.C % 64 != 0 and a.C >= 16 and a.data is None and not hasattr(a, 'C_real') and a.consumers and _pad_ok(a):
         a.C_real = a.C
         a.C = (a.C + 63) // 64 * 64
 
@@ -580,7 +615,7 @@ class DCEngine(FlatParamEngine):
             a = by_name[n]
             t = torch.empty(self.B, a.C, a.H, a.W, dtype=torch.float32, device=self.dev)
             K.nhwc_to_nchw(a.data, t)
-            res[n] = t
+            res[n] = t[:, :getattr(a, 'C_real', a.C)]           # drop the zero channels of a padded record
         return res
 
 
