@@ -118,7 +118,7 @@ _PROTOS = {
                                   c_void_p]),
     'adn_binpred_bwd': (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_float, c_float, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_void_p]),
-    'adn_dropout_mask': (C.c_int, [c_void_p, c_int64, c_float, C.c_uint64, c_void_p]),
+    'adn_dropout_mask': (C.c_int, [c_void_p, c_int64, c_float, C.c_uint64, c_void_p, c_void_p]),
     'adn_bcast_add': (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_int32, c_int32, c_void_p]),
     'adn_bins_fwd': (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     'adn_bins_bwd_workspace_bytes': (c_int64, [c_int32, c_int32, c_int32]),

@@ -16,6 +16,7 @@ import torch
 from . import _lib
 from . import kernels as K
 from .dc_engine import Act, ConvBNReLU, DCEngine, Head1x1, Op, flag_solo
+from .engine import GraphedStep
 from ._lib import EPI_ACT, EPI_ADD, GEMM_S1
 
 
@@ -106,7 +107,8 @@ class BinPredictor(Op):
         self.use_mask = bool(training and self.p > 0.0)
         if self.use_mask:
             self.draws += 1
-            K.dropout_mask(self.mask, self.p, eng.dropout_seed * 1000003 + self.draws * 2 + br.index)
+            K.dropout_mask(self.mask, self.p, eng.dropout_seed * 1000003 + self.draws * 2 + br.index,
+                           eng.step_counter)
         W1, b1, W2, b2 = self._params(eng)
         K.binpred_fwd(br.g, W1, b1, W2, b2, self.mask if self.use_mask else None, self.p, self.mod.max_depth, br.h1,
                       br.widths, br.centers)
@@ -156,6 +158,7 @@ class AdaBinsEngine(DCEngine):
     def __init__(self, module, compute_dtype=torch.bfloat16):
         super().__init__(module, None, compute_dtype, 'AdaBinsDistillationModel')
         self.dropout_seed = 0
+        self.step_counter = None     # device f64[1] step count (the trainer's optimizer state): fresh dropout per replay
         self.feat_coef = None
         self.feat_stats = None
         self.branches = {}
@@ -328,7 +331,7 @@ def _update_again(self, eng):
 ConvBNReLU.update_running_stats_again = _update_again
 
 
-class AdaBinsTrainer:
+class AdaBinsTrainer(GraphedStep):
     """One fused distillation step: teacher forward, student forward, DistillationLoss, student backward,
     clip_grad_norm_(1.0), AdamW -- train_adabins_distillation.py:445-456 with the loss weights of :179-188."""
 
@@ -363,6 +366,7 @@ class AdaBinsTrainer:
         self.norm_ws = torch.empty(1024 + 8, **f64)
         self.exp_avg = torch.zeros_like(eng.flat_p)
         self.exp_avg_sq = torch.zeros_like(eng.flat_p)
+        eng.step_counter = self.state
         self._ready = True
 
     def state_dict(self):
@@ -383,7 +387,11 @@ class AdaBinsTrainer:
             self.state[0] = float(sd['step'])
 
     def step(self, audio, rgb, gt):
-        """audio [B,2,H,W], rgb [B,3,H,W] or None, gt [B,1,H,W] -> (total loss 0-dim device tensor, terms f32[8])."""
+        """audio [B,2,H,W], rgb [B,3,H,W] or None, gt [B,1,H,W] -> (total loss 0-dim device tensor, terms f32[8]).
+        With ``enable_graph()`` the step replays as one hipGraph (the dropout draw mixes in the device-side step count)."""
+        return self._graphed(audio, rgb, gt)
+
+    def _step_impl(self, audio, rgb, gt):
         eng = self.engine
         m = eng.module
         eng._prepare_branches(audio.shape[0], audio.shape[2], audio.shape[3], audio.device)

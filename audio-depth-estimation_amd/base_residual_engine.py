@@ -12,6 +12,7 @@ import torch
 
 from . import kernels as K
 from .dc_engine import DCEngine, Head1x1, flag_solo
+from .engine import GraphedStep
 
 
 class BaseResidualEngine(DCEngine):
@@ -104,7 +105,7 @@ class BaseResidualEngine(DCEngine):
                 op.bwd(self)
 
 
-class BaseResidualTrainer:
+class BaseResidualTrainer(GraphedStep):
     """One fused step of train_base_residual.py:375-388: forward, BaseResidualLoss (valid = gt > 0), backward,
     clip_grad_norm_(1.0), optimizer."""
 
@@ -160,6 +161,9 @@ class BaseResidualTrainer:
 
     def step(self, x, gt):
         """Returns (total loss 0-dim device tensor, terms f32[4] = weighted recon, mean|base-struct|, mean|res|, total)."""
+        return self._graphed(x, gt)
+
+    def _step_impl(self, x, gt):
         eng = self.engine
         base, resid, final = eng.forward_net(x, True)
         gt = gt.contiguous().float()

@@ -230,7 +230,9 @@ __global__ __launch_bounds__(256) void bcast_add_kernel(void* gx, const float* d
 }
 
 // Bernoulli keep mask from a counter-based hash (one draw per element and step; not torch's RNG stream)
-__global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* mask, int64_t n, float p, uint64_t seed) {
+__global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* mask, int64_t n, float p, uint64_t seed,
+                                                           const double* counter) {
+  if (counter) seed += 0xD1B54A32D192ED03ull * (uint64_t)(counter[0] + 1.0);     // device-side step count: graph-replay safe
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
     uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(e + 1);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -544,10 +546,10 @@ extern "C" int adn_binpred_bwd(const float* dcent, const float* widths, const fl
   return ADN_OK;
 }
 
-extern "C" int adn_dropout_mask(uint8_t* mask, int64_t n, float p, uint64_t seed, void* stream) {
+extern "C" int adn_dropout_mask(uint8_t* mask, int64_t n, float p, uint64_t seed, const double* counter, void* stream) {
   ADN_CHECK_ARG(mask && n > 0 && p >= 0.f && p < 1.f, "adn_dropout_mask: bad arguments");
   hipLaunchKernelGGL(dropout_mask_kernel, dim3(blocks_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), mask, n,
-                     p, seed);
+                     p, seed, counter);
   ADN_CHECK_LAUNCH();
   return ADN_OK;
 }

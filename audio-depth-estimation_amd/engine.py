@@ -354,6 +354,37 @@ def run_unet(engine, x, training):
         return engine.forward(x, training).clone()
 
 
+class GraphedStep:
+    """Launch-overhead removal shared by the fused trainers: after ``after_steps`` eager steps the whole step (a few
+    hundred libadn launches, nothing synchronising with the host) is captured into ONE hipGraph over static input
+    buffers and replayed.  Subclasses implement ``_step_impl(*inputs)`` (inputs may be None) and return device
+    tensors that stay valid across replays."""
+    _graph = None
+    _graph_after = None
+    _calls = 0
+
+    def enable_graph(self, after_steps=3):
+        self._graph_after = after_steps
+
+    def _graphed(self, *inputs):
+        self._calls += 1
+        if self._graph is not None:
+            for buf, t in zip(self._g_in, inputs):
+                if buf is not None:
+                    buf.copy_(t)
+            self._graph.replay()
+            return self._g_out
+        if self._graph_after is not None and self._calls > self._graph_after:
+            self._g_in = [None if t is None else t.contiguous().float().clone() for t in inputs]
+            torch.cuda.synchronize()
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._g_out = self._step_impl(*self._g_in)
+            self._graph.replay()            # capture only records: run the step once for real
+            return self._g_out
+        return self._step_impl(*inputs)
+
+
 class FusedTrainer:
     """One fused training step: forward + masked loss + backward + (all-reduce) + clip + optimizer.
 

@@ -501,9 +501,10 @@ def binpred_bwd(dcent, widths, h1, g, W1, W2, has_mask, drop_p, max_depth, dW2p,
               float(drop_p), float(max_depth), B, Cb, Hd, nb, ptr(dW2p), ptr(db2p), ptr(dW1p), ptr(db1p), ptr(dg), _stream())
 
 
-def dropout_mask(mask, p, seed):
-    _dev(mask)
-    _lib.call('adn_dropout_mask', ptr(mask), mask.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, _stream())
+def dropout_mask(mask, p, seed, counter=None):
+    _dev(mask, counter)
+    _lib.call('adn_dropout_mask', ptr(mask), mask.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(counter),
+              _stream())
 
 
 def bcast_add(gx, dg, scale, accumulate):

@@ -245,8 +245,9 @@ int adn_binpred_bwd(const float* dcent, const float* widths, const float* h1, co
                     int32_t B, int32_t Cb, int32_t Hd, int32_t nb, float* dW2p, float* db2p, float* dW1p,
                     float* db1p, float* dg, void* stream);
 /* Bernoulli(1-p) keep mask from a counter-based hash of (seed, index): nn.Dropout(0.1) :144 (statistically
- * equivalent draw; torch's RNG stream is not reproducible from outside torch). */
-int adn_dropout_mask(uint8_t* mask, int64_t n, float p, uint64_t seed, void* stream);
+ * equivalent draw; torch's RNG stream is not reproducible from outside torch).  counter (optional, device f64[1],
+ * e.g. the optimizer's step count) is mixed into the seed ON THE DEVICE so that a hipGraph replay draws a fresh mask. */
+int adn_dropout_mask(uint8_t* mask, int64_t n, float p, uint64_t seed, const double* counter, void* stream);
 /* gx [B][HW][C] (+)= scale * dg [B][C]: backward of the average pool. */
 int adn_bcast_add(void* gx, const float* dg, int32_t B, int32_t HW, int32_t C, float scale,
                   int32_t accumulate, int32_t dtype, void* stream);

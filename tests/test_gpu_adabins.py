@@ -79,6 +79,11 @@ def test_dropout_mask_statistics():
     assert float((m != m2).float().mean()) > 0.1          # a different seed gives a different draw
     k.dropout_mask(m2, 0.1, 12345)
     assert torch.equal(m, m2)                             # same seed: same draw (replayable)
+    cnt = torch.zeros(1, dtype=torch.float64, device=DEV)
+    k.dropout_mask(m, 0.1, 12345, cnt)
+    cnt += 1                                              # device-side step count: the next (graph) replay differs
+    k.dropout_mask(m2, 0.1, 12345, cnt)
+    assert float((m != m2).float().mean()) > 0.1 and abs(float(m2.float().mean()) - 0.9) < 2e-3
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
@@ -268,3 +273,30 @@ def test_distillation_loss_module_and_adaptive_schedule():
     assert tr.lambdas[0] == 3.0 and tr.temperature == 4.0
     with pytest.raises(RuntimeError):
         model(audio.cpu(), rgb=None, mode='inference')
+
+
+def test_adabins_graph_step_matches_eager():
+    """hipGraph replay of the fused distillation step == eager launches from the same state (dropout p = 0)."""
+    from audio_depth_estimation_amd.adabins_engine import AdaBinsTrainer
+    from audio_depth_estimation_amd.models.adabins_distillation_model import AdaBinsDistillationModel
+    g = torch.Generator().manual_seed(5)
+    audio, rgb = torch.rand(2, 2, 32, 32, generator=g).to(DEV), torch.rand(2, 3, 32, 32, generator=g).to(DEV)
+    gt = (30 * torch.rand(2, 1, 32, 32, generator=g)).to(DEV)
+    finals = []
+    for graph in (False, True):
+        torch.manual_seed(0)
+        model = AdaBinsDistillationModel(128, 64, 32, 30.0)
+        for m in model.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        model.compute_dtype = torch.bfloat16
+        model = model.to(DEV).train()
+        tr = AdaBinsTrainer(model.engine(), lr=1e-3)
+        if graph:
+            tr.enable_graph(after_steps=2)
+        for _ in range(5):
+            loss, _ = tr.step(audio, rgb, gt)
+        torch.cuda.synchronize()
+        finals.append((float(loss), model.engine().flat_p.detach().clone()))
+    assert abs(finals[1][0] - finals[0][0]) <= 1e-6 * abs(finals[0][0])
+    assert torch.equal(finals[0][1], finals[1][1])

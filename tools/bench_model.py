@@ -63,6 +63,9 @@ def adabins_main(args, dev, dtype, gt, g):
     for name, (ms, fl, n) in sorted(fam.items(), key=lambda kv: -kv[1][0]):
         tf = f'{fl / (ms * 1e-3) / 1e12:9.1f}' if fl else '         '
         print(f'{name:34s} {ms:9.3f} {n:9d} {tf}')
+    (inner if args.model == 'baseres' else tr).enable_graph(after_steps=0)
+    tr.step(audio, rgb, gt)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, _ = tr.step(audio, rgb, gt)
