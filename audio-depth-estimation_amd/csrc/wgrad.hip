@@ -32,7 +32,7 @@ __device__ u32x4_t adn_wg_zero_page[8];
 
 __device__ __forceinline__ int swz_f(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
-template <typename T, bool FAST, bool MIXED, bool S1>
+template <typename T, bool FAST, bool MIXED, bool S1, bool HALF>
 __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins exist only in the device pass
   constexpr int EPC = 16 / (int)sizeof(T);
@@ -48,7 +48,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
   char* Gs = smem + 2 * TILE;      // [2][TILE]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  // HALF (R == 64): all four waves work on rows 0..63 -- 2 column halves x 2 halves of every pixel step -- instead of
+  // two of them multiplying the zero upper half of the row tile; the two pixel halves are summed in the epilogue
+  const int wr = HALF ? 0 : (wave >> 1), wc = wave & 1;
+  const int kh = wave >> 1;
   // XCD-contiguous order: all output tiles of one pixel split run on the same XCD and share the staged
   // operands through its L2 (blocks b and b+8 share an XCD)
   const int ntile = p.tiles_r * p.tiles_c;
@@ -251,6 +254,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
       const int q = (lane & 15) >> 2, pp = lane & 3;
 #pragma unroll
       for (int ks = 0; ks < BKP / 32; ++ks) {
+        if (HALF && ks != kh) continue;
         bf16x8_t af[4], bf[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -289,6 +293,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
     } else {
 #pragma unroll
       for (int ks = 0; ks < BKP / 4; ++ks) {
+        if (HALF && (ks >> 2) != kh) continue;
         const int row = ks * 4 + fg;
         float af[4], bf[4];
 #pragma unroll
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) ct[(wr * 64 + i * 16 + 4 * fg + r) * LDC + wc * 64 + j * 16 + fi] = acc[i][j][r];
+      for (int r = 0; r < 4; ++r) ct[((HALF ? kh : wr) * 64 + i * 16 + 4 * fg + r) * LDC + wc * 64 + j * 16 + fi] = acc[i][j][r];
   __syncthreads();
   float* out = p.out + (int64_t)split * p.out_elems;
   const int cq = tid & 31;    // float4 column group (32 per row)
@@ -328,7 +333,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
     for (int k = 0; k < 16; ++k) {
       const int row = r0 + 8 * k;
       if (cok && tile_r * 128 + row < R) {
-        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(ct + row * LDC + cq * 4);
+        f32x4_t v = *reinterpret_cast<const f32x4_t*>(ct + row * LDC + cq * 4);
+        if (HALF) v += *reinterpret_cast<const f32x4_t*>(ct + (row + 64) * LDC + cq * 4);     // second pixel half
         *reinterpret_cast<f32x4_t*>(out + (int64_t)(tile_r * 128 + row) * ldo + tile_c * 128 + cq * 4) = v;
       }
     }
@@ -341,7 +347,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
         const int gc = tile_c * 128 + cq * 4 + e;
         const int tp = gc / C, cc = gc - tp * C;
         if (tp < ntap && cc < p.c_valid)
-          out[((int64_t)(tile_r * 128 + row) * ntap + tp) * p.c_valid + cc] = ct[row * LDC + cq * 4 + e];
+          out[((int64_t)(tile_r * 128 + row) * ntap + tp) * p.c_valid + cc] =
+              ct[row * LDC + cq * 4 + e] + (HALF ? ct[(row + 64) * LDC + cq * 4 + e] : 0.f);
       }
     }
   }
@@ -495,15 +502,21 @@ int wrun(const AdnWgradDesc* d, const WPlan& pl, hipStream_t st) {
     constexpr int lds = stage > epil ? stage : epil;
     const dim3 grid(pl.tiles_r * pl.tiles_c * pl.nsplit);
     const bool s1 = d->geom == ADN_GEMM_S1;
-#define ADN_WG_LAUNCH(FAST_, MIXED_, S1_)                                                                      \
+    const bool half = (d->R0 + d->R1) == 64;
+#define ADN_WG_LAUNCH1(FAST_, MIXED_, S1_, HALF_)                                                                      \
   do {                                                                                                         \
     static bool attr_set = false;                                                                              \
     if (!attr_set) {                                                                                           \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_kernel<T, FAST_, MIXED_, S1_>),      \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_kernel<T, FAST_, MIXED_, S1_, HALF_>),      \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds);                              \
       attr_set = true;                                                                                         \
     }                                                                                                          \
-    hipLaunchKernelGGL((wgrad_mfma_kernel<T, FAST_, MIXED_, S1_>), grid, dim3(256), lds, st, p);               \
+    hipLaunchKernelGGL((wgrad_mfma_kernel<T, FAST_, MIXED_, S1_, HALF_>), grid, dim3(256), lds, st, p);        \
+  } while (0)
+#define ADN_WG_LAUNCH(FAST_, MIXED_, S1_)                  \
+  do {                                                     \
+    if (half) ADN_WG_LAUNCH1(FAST_, MIXED_, S1_, true);    \
+    else ADN_WG_LAUNCH1(FAST_, MIXED_, S1_, false);        \
   } while (0)
     if (pl.fast && pl.mixed) {
       if (s1) ADN_WG_LAUNCH(true, true, true);
@@ -516,6 +529,7 @@ int wrun(const AdnWgradDesc* d, const WPlan& pl, hipStream_t st) {
       else ADN_WG_LAUNCH(false, false, false);
     }
 #undef ADN_WG_LAUNCH
+#undef ADN_WG_LAUNCH1
   } else {
     hipLaunchKernelGGL((wgrad_direct_kernel<T>), dim3((unsigned)adn_cdiv(pl.out_elems, 256), pl.nsplit), dim3(256),
                        0, st, p, pl.pix_per_split);
