@@ -1,0 +1,132 @@
+"""Two ranks on ONE GPU (gloo collectives on device tensors) through the real fused trainers: the N > 1 path of
+bench.py / train*.py with the HIP engines instead of the fake engine of test_ddp_gloo.py.
+
+Checked per model (U-Net baseline, RGBDepthNet): after three fused steps on different shards the replicas hold
+bit-identical parameters (same SUM-reduced gradients, same optimizer), and the first step equals what ONE process
+computes when it runs both shards through two engines sharing the weights, sums their gradients and applies one
+optimizer step with the global-batch loss -- DataParallel semantics with per-replica BatchNorm.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _make(kind):
+    from types import SimpleNamespace
+    torch.manual_seed(0)
+    if kind == 'unet':
+        from audio_depth_estimation_amd.models.unetbaseline_model import define_G
+        m = define_G(SimpleNamespace(dataset=SimpleNamespace(depth_norm=False)), 2, 1, 64, 'unet_128')
+        with torch.no_grad():
+            m.model.model[3].bias.fill_(1.0)
+        targs = dict(criterion='Combined', l1_weight=0.237, silog_weight=0.637, silog_lambda=0.869, clip_norm=1.0, lr=2e-3)
+        cin = 2
+    else:
+        from audio_depth_estimation_amd.models.rgb_depth_model import RGBDepthNet
+        m = RGBDepthNet(32, True, 128, 30.0)
+        targs = dict(criterion='DepthLoss', l1_weight=1.0, silog_weight=0.1, clip_norm=None, lr=1e-3, weight_decay=0.01)
+        cin = 3
+    m.compute_dtype = torch.float32
+    return m.to('cuda').train(), targs, cin
+
+
+def _shard(rank, cin, B=2, S=128):
+    g = torch.Generator().manual_seed(100 + rank)
+    x = torch.rand(B, cin, S, S, generator=g)
+    gt = 30 * torch.rand(B, 1, S, S, generator=g)
+    gt[gt < (3 + 6 * rank)] = 0
+    return x.to('cuda'), gt.to('cuda')
+
+
+def _worker(rank, world, port, kind, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from audio_depth_estimation_amd.ddp import GradientAllReducer
+        from audio_depth_estimation_amd.engine import FusedTrainer
+        model, targs, cin = _make(kind)
+        red = GradientAllReducer(bucket_bytes=1 << 20)
+        tr = FusedTrainer(model.engine(), ddp=red, **targs)
+        model.engine().bind_parameters()
+        red.broadcast_parameters(model.engine().flat_p)
+        x, gt = _shard(rank, cin)
+        loss, _ = tr.step(x, gt)
+        loss = float(loss)                                # (the returned 0-dim tensor is a view of the trainer's buffer)
+        first = model.engine().flat_p.detach().cpu().clone()
+        for _ in range(2):
+            tr.step(x, gt)
+        torch.cuda.synchronize()
+        out.put((rank, loss, first.numpy().tobytes(), model.engine().flat_p.detach().cpu().numpy().tobytes()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('kind', ['unet', 'rgb'])
+def test_two_ranks_one_gpu(kind):
+    import numpy as np
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, kind, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, l0, f0, p0), (_, l1, f1, p1) = res
+    assert l0 == l1                                   # one global-batch loss on both ranks
+    assert p0 == p1                                   # replicas stay bit-identical
+    # single-process emulation of the first step: two engines (one per shard) sharing the initial weights
+    from audio_depth_estimation_amd import kernels as K
+    from audio_depth_estimation_amd.engine import FusedTrainer
+    ma, targs, cin = _make(kind)
+    mb, _, _ = _make(kind)
+    ea, eb = ma.engine(), mb.engine()
+    ea.bind_parameters()
+    eb.bind_parameters()
+    shards = [_shard(0, cin), _shard(1, cin)]
+    preds = [ea.forward(shards[0][0], True).clone(), eb.forward(shards[1][0], True).clone()]
+    tr = FusedTrainer(ea, **targs)
+    tr._setup(preds[0].device)
+    stats = torch.zeros(4, dtype=torch.float64, device='cuda')
+    tot = torch.zeros(4, dtype=torch.float64, device='cuda')
+    crit = tr.criterion
+    for (x, gt), pr in zip(shards, preds):
+        if crit == 3:
+            K.l1tv_stats(pr, gt, stats, tr.loss_ws)
+        else:
+            K.loss_stats(pr, gt, 1.0, tr.mask_mode, 1e-6, stats, tr.loss_ws)
+        tot += stats
+    gouts = []
+    for (x, gt), pr in zip(shards, preds):
+        go = torch.empty_like(pr)
+        if crit == 3:
+            K.l1tv_finish(pr, gt, tot, 2, tr.l1_weight, tr.silog_weight, tr.loss, go)
+        else:
+            K.loss_finish(pr, gt, 1.0, tr.mask_mode, 1e-6, tot, crit, tr.l1_weight, tr.silog_weight, tr.silog_lambda, tr.loss, go)
+        gouts.append(go)
+    ea.backward(gouts[0])
+    eb.backward(gouts[1])
+    ea.flat_g += eb.flat_g
+    if tr.clip_norm is not None:
+        K.grad_norm(ea.flat_g, float(tr.clip_norm), tr.state, tr.norm_ws)
+    K.optimizer_step(ea.flat_p, ea.flat_g, tr.exp_avg, tr.exp_avg_sq, tr.opt_kind, tr.lr, tr.betas[0], tr.betas[1], tr.eps,
+                     tr.weight_decay, tr.clip_norm is not None, tr.state, bf16_copy=ea.flat_w16)
+    want = ea.flat_p.detach().cpu().numpy()
+    got = np.frombuffer(f0, dtype=np.float32)
+    assert abs(float(tr.loss) - l0) <= 1e-6 * abs(l0)
+    # BN running statistics are per replica (rank 0 = shard 0): parameters (incl. them) must agree with engine a
+    assert float(np.abs(got - want).max()) <= 1e-6 + 0.02 * tr.lr
