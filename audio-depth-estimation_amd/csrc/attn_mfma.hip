@@ -96,18 +96,16 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(FParams p) {
   const int q4 = li >> 2, pp = li & 3;
   for (int kt = 0; kt < nkt; ++kt) {
     // ---- S^T = K Q^T : st[t][u][r] = score(query 16t + li, key 16u + 4g + r)
-    f32x4_t st[QT][4];
-#pragma unroll
-    for (int t = 0; t < QT; ++t)
-#pragma unroll
-      for (int u = 0; u < 4; ++u) st[t][u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    f32x4_t st[QT][4];          // (the first MFMA of every chain takes the literal 0 as C: no accumulator zeroing)
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int s = 0; s < KS; ++s)
+      for (int t = 0; t < QT; ++t) {
+        st[t][u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kf[u][0], qf[t][0], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < QT; ++t)
+        for (int s = 1; s < KS; ++s)
           st[t][u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kf[u][s], qf[t][s], st[t][u], 0, 0, 0);
+      }
 
     // ---- online softmax; probabilities packed as the A operand of the PV MFMA
     bf16x8_t pa[QT][2];
@@ -347,18 +345,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(BParams p) {
   stage_narrow<DQK>(Kp, p.ld_k, 0, ksm, wave, lane);
   load_k(0);
   for (int kt = 0; kt < nkt; ++kt) {
-    f32x4_t st[QT][4];
-#pragma unroll
-    for (int t = 0; t < QT; ++t)
-#pragma unroll
-      for (int u = 0; u < 4; ++u) st[t][u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    f32x4_t st[QT][4];          // (the first MFMA of every chain takes the literal 0 as C: no accumulator zeroing)
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int s = 0; s < KS; ++s)
+      for (int t = 0; t < QT; ++t) {
+        st[t][u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kf[u][0], qf[t][0], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < QT; ++t)
+        for (int s = 1; s < KS; ++s)
           st[t][u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kf[u][s], qf[t][s], st[t][u], 0, 0, 0);
+      }
     __syncthreads();
     if (kt + 1 < nkt) {
       stage_wide<DV>(Vp, p.ld_v, (kt + 1) * 64, vs + ((kt + 1) & 1) * VT, wave, lane);
@@ -370,10 +366,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(BParams p) {
     // dP^T = V dO^T : A = V[key 16u + li][32c + 8g ..+7] (16-byte LDS reads), B = dO fragments
     f32x4_t dp[QT][4];
 #pragma unroll
-    for (int t = 0; t < QT; ++t)
-#pragma unroll
-      for (int u = 0; u < 4; ++u) dp[t][u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int row = 16 * u + li;
 #pragma unroll
@@ -381,7 +373,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(BParams p) {
         const int pn = c >> 2, gi = 2 * (c & 3) + (g >> 1);
         const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(Vb + pn * PANEL + row * 256 + ((gi ^ vswz(row)) << 5) + (g & 1) * 16);
 #pragma unroll
-        for (int t = 0; t < QT; ++t) dp[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[t][c], dp[t][u], 0, 0, 0);
+        for (int t = 0; t < QT; ++t)
+          dp[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[t][c], c == 0 ? f32x4_t{0.f, 0.f, 0.f, 0.f} : dp[t][u], 0, 0, 0);
       }
     }
     // dS^T = P (dP - D) scale, packed as the A operand (k-slots = keys)
@@ -423,7 +416,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(BParams p) {
 }
 
 template <int DQK, int DV, int KT>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(BParams p) {
+__global__ __launch_bounds__(256, DQK == 16 ? 2 : 1) void attn_bwd_dkv_mfma_kernel(BParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int NP = DV / 128, PANEL = 64 * 256, VT = NP * PANEL, QTB = 64 * DQK * 2;
   constexpr int KS = DQK / 16, CK = DV / 32, CB = DV / 16, DB = DQK / 16;
@@ -460,86 +453,74 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(BParams p) {
 #pragma unroll
     for (int d = 0; d < DB; ++d) dka[t][d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
-  s16x4_t qf[4][KS];
+  // log-sum-exp and delta of the 64 queries of a tile: 16 + 16 floats per lane (rows 16u + 4g + r), reloaded for the
+  // next tile as soon as the half that used them is done, so only one copy is ever live
   f32x4_t lq[4], dq4[4];
-  auto load_q = [&](int qt) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-#pragma unroll
-      for (int s = 0; s < KS; ++s)
-        qf[u][s] = *reinterpret_cast<const s16x4_t*>(Q + (int64_t)(qt * 64 + 16 * u + li) * p.ld_q + 16 * s + 4 * g);
-      lq[u] = *reinterpret_cast<const f32x4_t*>(lse + qt * 64 + 16 * u + 4 * g);
-      dq4[u] = *reinterpret_cast<const f32x4_t*>(dsum + qt * 64 + 16 * u + 4 * g);
-    }
+  auto load_ld = [&](int qt, int u) {
+    lq[u] = *reinterpret_cast<const f32x4_t*>(lse + qt * 64 + 16 * u + 4 * g);
+    dq4[u] = *reinterpret_cast<const f32x4_t*>(dsum + qt * 64 + 16 * u + 4 * g);
   };
   const int nqt = p.N / 64;
   stage_wide<DV>(DO, p.ld_do, 0, dos, wave, lane);
   stage_narrow<DQK>(Q, p.ld_q, 0, qsm, wave, lane);
-  load_q(0);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) load_ld(0, u);
   for (int qt = 0; qt < nqt; ++qt) {
-    // S = Q K^T : st[t][u][r] = score(query 16u + 4g + r, key 16t + li)
-    f32x4_t st[KT][4];
-#pragma unroll
-    for (int t = 0; t < KT; ++t)
-#pragma unroll
-      for (int u = 0; u < 4; ++u) st[t][u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int s = 0; s < KS; ++s)
-#pragma unroll
-        for (int t = 0; t < KT; ++t)
-          st[t][u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qf[u][s], kfr[t][s], st[t][u], 0, 0, 0);
-    f32x4_t l2[4], d4[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      l2[u] = lq[u] * 1.4426950408889634f;
-      d4[u] = dq4[u];
-    }
-    __syncthreads();
-    if (qt + 1 < nqt) {
+    __syncthreads();          // tile qt has landed (vmcnt(0) in front of the barrier); tile qt-1 is no longer read
+    const bool more = qt + 1 < nqt;
+    if (more) {
       stage_wide<DV>(DO, p.ld_do, (qt + 1) * 64, dos + ((qt + 1) & 1) * VT, wave, lane);
       stage_narrow<DQK>(Q, p.ld_q, (qt + 1) * 64, qsm + ((qt + 1) & 1) * QTB, wave, lane);
-      load_q(qt + 1);
     }
     const char* Db = dos + (qt & 1) * VT;
     const char* Qb = qsm + (qt & 1) * QTB;
-    // dP = dO V^T : A = dO[query 16u + li][32c + 8g ..] (16-byte LDS reads), B = V fragments
-    f32x4_t dp[KT][4];
-#pragma unroll
-    for (int t = 0; t < KT; ++t)
-#pragma unroll
-      for (int u = 0; u < 4; ++u) dp[t][u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int row = 16 * u + li;
-#pragma unroll
-      for (int c = 0; c < CK; ++c) {
-        const int pn = c >> 2, gi = 2 * (c & 3) + (g >> 1);
-        const bf16x8_t df = *reinterpret_cast<const bf16x8_t*>(Db + pn * PANEL + row * 256 + ((gi ^ vswz(row)) << 5) + (g & 1) * 16);
-#pragma unroll
-        for (int t = 0; t < KT; ++t) dp[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vfr[t][c], dp[t][u], 0, 0, 0);
-      }
-    }
-    bf16x8_t pa[KT][2], dsa[KT][2];
-#pragma unroll
-    for (int t = 0; t < KT; ++t) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pv = __builtin_amdgcn_exp2f(st[t][u][r] * p.sc2 - l2[u][r]);
-          st[t][u][r] = pv;
-          dp[t][u][r] = pv * (dp[t][u][r] - d4[u][r]) * p.scale;
-        }
-      pa[t][0] = pack8(st[t][0], st[t][1]);
-      pa[t][1] = pack8(st[t][2], st[t][3]);
-      dsa[t][0] = pack8(dp[t][0], dp[t][1]);
-      dsa[t][1] = pack8(dp[t][2], dp[t][3]);
-    }
-    // dV += P^T dO, dK += dS^T Q : k-slots are queries 32h + 4g + j / 32h + 16 + 4g + (j - 4)
+    // the tile is processed in two halves of 32 queries (= one K step of the dV / dK products), so that only the
+    // scores of one half are live and the exp / dS math of a half overlaps the MFMAs of the other
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
+      // S = Q K^T, dP = dO V^T : st[t][uu][r] = score(query 32h + 16uu + 4g + r, key 16t + li)
+      f32x4_t st[KT][2], dp[KT][2];
+#pragma unroll
+      for (int uu = 0; uu < 2; ++uu) {
+        const int row = 32 * h + 16 * uu + li;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const s16x4_t qv = *reinterpret_cast<const s16x4_t*>(Qb + row * (DQK * 2) + ((s ^ sswz<DQK>(row)) << 5) + 8 * g);
+#pragma unroll
+          for (int t = 0; t < KT; ++t)
+            st[t][uu] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qv, kfr[t][s], s == 0 ? f32x4_t{0.f, 0.f, 0.f, 0.f} : st[t][uu], 0, 0, 0);
+        }
+#pragma unroll
+        for (int c = 0; c < CK; ++c) {
+          const int pn = c >> 2, gi = 2 * (c & 3) + (g >> 1);
+          const bf16x8_t df = *reinterpret_cast<const bf16x8_t*>(Db + pn * PANEL + row * 256 + ((gi ^ vswz(row)) << 5) + (g & 1) * 16);
+#pragma unroll
+          for (int t = 0; t < KT; ++t)
+            dp[t][uu] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vfr[t][c], c == 0 ? f32x4_t{0.f, 0.f, 0.f, 0.f} : dp[t][uu], 0, 0, 0);
+        }
+      }
+      bf16x8_t pa[KT], dsa[KT];
+#pragma unroll
+      for (int t = 0; t < KT; ++t) {
+#pragma unroll
+        for (int uu = 0; uu < 2; ++uu) {
+          const f32x4_t l2 = lq[2 * h + uu] * 1.4426950408889634f;
+          const f32x4_t d4 = dq4[2 * h + uu];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pv = __builtin_amdgcn_exp2f(st[t][uu][r] * p.sc2 - l2[r]);
+            st[t][uu][r] = pv;
+            dp[t][uu][r] = pv * (dp[t][uu][r] - d4[r]) * p.scale;
+          }
+        }
+        pa[t] = pack8(st[t][0], st[t][1]);
+        dsa[t] = pack8(dp[t][0], dp[t][1]);
+      }
+      if (more) {
+        load_ld(qt + 1, 2 * h);
+        load_ld(qt + 1, 2 * h + 1);
+      }
+      // dV += P^T dO, dK += dS^T Q : k-slots are queries 32h + 4g + j / 32h + 16 + 4g + (j - 4)
       const int row_lo = 32 * h + 4 * g + q4, row_hi = row_lo + 16;
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) {
@@ -547,14 +528,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(BParams p) {
         const bf16x8_t bfr = tr_pair(Db + pn * PANEL + row_lo * 256 + ((cw ^ vswz(row_lo)) << 5) + pp * 8,
                                      Db + pn * PANEL + row_hi * 256 + ((cw ^ vswz(row_hi)) << 5) + pp * 8);
 #pragma unroll
-        for (int t = 0; t < KT; ++t) dva[t][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[t][h], bfr, dva[t][cb], 0, 0, 0);
+        for (int t = 0; t < KT; ++t) dva[t][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[t], bfr, dva[t][cb], 0, 0, 0);
       }
 #pragma unroll
       for (int d = 0; d < DB; ++d) {
         const bf16x8_t qfr = tr_pair(Qb + row_lo * (DQK * 2) + ((d ^ sswz<DQK>(row_lo)) << 5) + pp * 8,
                                      Qb + row_hi * (DQK * 2) + ((d ^ sswz<DQK>(row_hi)) << 5) + pp * 8);
 #pragma unroll
-        for (int t = 0; t < KT; ++t) dka[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsa[t][h], qfr, dka[t][d], 0, 0, 0);
+        for (int t = 0; t < KT; ++t) dka[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsa[t], qfr, dka[t][d], 0, 0, 0);
       }
     }
   }
