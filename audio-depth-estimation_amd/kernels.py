@@ -443,7 +443,7 @@ def _attn_desc(q, k, v, o, lse, dqk, dv, kv_shift, scale, dout=None, dq=None, dk
 def attn_fwd(q, k, v, o, lse, dqk, dv, kv_shift, scale):
     d = _attn_desc(q, k, v, o, lse, dqk, dv, kv_shift, scale)
     _lib.call('adn_attn_fwd', C.byref(d), _stream())
-    _lib.annotate(label='attn_fwd', flops=4.0 * d.B2 * d.N * d.N * (dqk + dv))
+    _lib.annotate(label='attn_fwd', flops=2.0 * d.B2 * d.N * d.N * (dqk + dv))
 
 
 def attn_bwd(q, k, v, o, lse, dqk, dv, kv_shift, scale, dout, dq, dk, dvg, workspace):

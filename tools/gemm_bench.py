@@ -143,7 +143,7 @@ def attn_main(args):
         sc = 1.0 / dv ** 0.5
         fn = lambda: K.attn_fwd(q, k, v, o, lse, dqk, dv, B2 // 2, sc)
         t = timeit(fn, args.iters)
-        fl = 4.0 * B2 * N * N * (dqk + dv)
+        fl = 2.0 * B2 * N * N * (dqk + dv)          # S = QK^T and O = PV
         print(f'{name}_fwd B2={B2:3d} N={N:6d} dqk={dqk:3d} dv={dv:4d}  {t*1e6:10.1f} us  {fl/t/1e12:7.1f} TF/s', flush=True)
         if args.bwd:
             do = torch.randn(B2, N, dv, device=DEV).to(T)
