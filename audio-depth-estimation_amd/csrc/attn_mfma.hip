@@ -205,45 +205,24 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_mfma_kernel(FParams p) {
     }
   };
 
-  // Software pipeline: the scores and the softmax of tile kt + 1 are independent of the P V product of tile kt, so
-  // both sit in one loop body and the exp / reduction chain of one hides under the MFMAs of the other.
+  // (A software-pipelined form - softmax of tile kt + 1 under the P V MFMAs of tile kt - needs 196 registers; the
+  //  third resident wave per SIMD that 160 registers allow is worth more: 7.5 vs 8.3 ms at B2 = 64, N = 16384.)
   issue_v(0, 0);
   load_k(0);
-  f32x4_t st[QT][4];
-  bf16x8_t pa[QT][2];
-  float al[QT];
-  scores(st);
-  load_k(nkt > 1 ? 1 : 0);
-  softmax_tile(st, pa, al);
-  for (int kt = 0; kt + 1 < nkt; ++kt) {
-    __syncthreads();        // V tile kt has landed (vmcnt(0) in front of the barrier); tile kt-1 is no longer read
-    issue_v(kt + 1, (kt + 1) & 1);
-    f32x4_t sn[QT][4];
-    scores(sn);                                         // tile kt + 1
-    load_k(kt + 2 < nkt ? kt + 2 : nkt - 1);            // (the last reload is a harmless repeat)
+  for (int kt = 0; kt < nkt; ++kt) {
+    f32x4_t st[QT][4];
+    bf16x8_t pa[QT][2];
+    float al[QT];
+    scores(st);
+    softmax_tile(st, pa, al);
     rescale(al);
-    bf16x8_t pn[QT][2];
-    float an[QT];
+    __syncthreads();        // V tile kt has landed (vmcnt(0) in front of the barrier); tile kt-1 is no longer read
+    if (kt + 1 < nkt) {
+      issue_v(kt + 1, (kt + 1) & 1);
+      load_k(kt + 1);
+    }
     pv_tile(smem + (kt & 1) * TILE, pa);
-    softmax_tile(sn, pn, an);
-    // ask the scheduler to spread the softmax VALU work between the MFMAs instead of behind them
-    constexpr int NM = QT * 2 * CB, VPM = (70 * QT) / NM > 0 ? (70 * QT) / NM : 1;
-#pragma unroll
-    for (int i = 0; i < NM; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // one MFMA
-      __builtin_amdgcn_sched_group_barrier(0x100, 2 / QT, 0);     // its transpose reads
-      __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);        // a slice of the VALU work
-    }
-#pragma unroll
-    for (int t = 0; t < QT; ++t) {
-      pa[t][0] = pn[t][0];
-      pa[t][1] = pn[t][1];
-      al[t] = an[t];
-    }
   }
-  __syncthreads();
-  rescale(al);
-  pv_tile(smem + ((nkt - 1) & 1) * TILE, pa);
 
   // ---- epilogue: O / l, lse
 #pragma unroll
