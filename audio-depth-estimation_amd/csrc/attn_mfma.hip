@@ -320,7 +320,7 @@ __device__ __forceinline__ void stage_narrow(const uint16_t* base, int ld, int r
 }
 
 template <int DQK, int DV, int QT>
-__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(BParams p) {
+__global__ __launch_bounds__(256, DQK == 16 ? 3 : 1) void attn_bwd_dq_mfma_kernel(BParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int NP = DV / 128, PANEL = 64 * 256, VT = NP * PANEL, KTB = 64 * DQK * 2;
   constexpr int KS = DQK / 16, CK = DV / 32, DB = DQK / 16;
@@ -391,43 +391,40 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(BParams p) {
     }
     const char* Vb = vs + (kt & 1) * VT;
     const char* Kb = ksm + (kt & 1) * KTB;
-    // dP^T = V dO^T : A = V[key 16u + li][32c + 8g ..+7] (16-byte LDS reads), B = dO fragments
-    f32x4_t dp[QT][4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int row = 16 * u + li;
-#pragma unroll
-      for (int c = 0; c < CK; ++c) {
-        const int pn = c >> 2, gi = 2 * (c & 3) + (g >> 1);
-        const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(Vb + pn * PANEL + row * 256 + ((gi ^ vswz(row)) << 5) + (g & 1) * 16);
-#pragma unroll
-        for (int t = 0; t < QT; ++t)
-          dp[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[t][c], c == 0 ? d0[t] : dp[t][u], 0, 0, 0);
-      }
-    }
-    // dS^T = P dP' , packed as the A operand (k-slots = keys)
-    bf16x8_t dsa[QT][2];
-#pragma unroll
-    for (int t = 0; t < QT; ++t) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          st[t][u][r] = __builtin_amdgcn_exp2f(st[t][u][r] * p.sc2) * dp[t][u][r];
-        }
-      dsa[t][0] = pack8(st[t][0], st[t][1]);
-      dsa[t][1] = pack8(st[t][2], st[t][3]);
-    }
-    // dQ += dS K : B[k = key][col = d] by transpose reads of the K tile
+    // dP^T = V dO^T : A = V[key 16u + li][32c + 8g ..+7] (16-byte LDS reads), B = dO fragments; then
+    // dS^T = P dP' packed as the A operand (k-slots = keys) and dQ += dS K (B[k = key][col = d] by transpose reads
+    // of the K tile).  Two halves of 32 keys keep only half of dP' live.
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
+      f32x4_t dp[QT][2];
+#pragma unroll
+      for (int uu = 0; uu < 2; ++uu) {
+        const int row = 32 * h + 16 * uu + li;
+#pragma unroll
+        for (int c = 0; c < CK; ++c) {
+          const int pn = c >> 2, gi = 2 * (c & 3) + (g >> 1);
+          const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(Vb + pn * PANEL + row * 256 + ((gi ^ vswz(row)) << 5) + (g & 1) * 16);
+#pragma unroll
+          for (int t = 0; t < QT; ++t)
+            dp[t][uu] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[t][c], c == 0 ? d0[t] : dp[t][uu], 0, 0, 0);
+        }
+      }
+      bf16x8_t dsa[QT];
+#pragma unroll
+      for (int t = 0; t < QT; ++t) {
+#pragma unroll
+        for (int uu = 0; uu < 2; ++uu)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dp[t][uu][r] *= __builtin_amdgcn_exp2f(st[t][2 * h + uu][r] * p.sc2);
+        dsa[t] = pack8(dp[t][0], dp[t][1]);
+      }
       const int row_lo = 32 * h + 4 * g + q4, row_hi = row_lo + 16;
 #pragma unroll
       for (int d = 0; d < DB; ++d) {
         const bf16x8_t kfr = tr_pair(Kb + row_lo * (DQK * 2) + ((d ^ sswz<DQK>(row_lo)) << 5) + pp * 8,
                                      Kb + row_hi * (DQK * 2) + ((d ^ sswz<DQK>(row_hi)) << 5) + pp * 8);
 #pragma unroll
-        for (int t = 0; t < QT; ++t) dqa[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsa[t][h], kfr, dqa[t][d], 0, 0, 0);
+        for (int t = 0; t < QT; ++t) dqa[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsa[t], kfr, dqa[t][d], 0, 0, 0);
       }
     }
   }
