@@ -331,14 +331,23 @@ def _update_again(self, eng):
 ConvBNReLU.update_running_stats_again = _update_again
 
 
+class _GradView:
+    """What ddp.GradientAllReducer.attach binds to: a flat gradient range and the grad-ready hook slot."""
+
+    def __init__(self, flat_g):
+        self.flat_g = flat_g
+        self.on_grad_ready = None
+
+
 class AdaBinsTrainer(GraphedStep):
     """One fused distillation step: teacher forward, student forward, DistillationLoss, student backward,
     clip_grad_norm_(1.0), AdamW -- train_adabins_distillation.py:445-456 with the loss weights of :179-188."""
 
     def __init__(self, engine, lambda_task=1.0, lambda_response=0.5, lambda_feature=0.3, lambda_bin=0.2,
                  lambda_sparse=0.1, temperature=4.0, optimizer='AdamW', lr=1e-4, betas=(0.9, 0.999), eps=1e-8,
-                 weight_decay=None, clip_norm=1.0):
+                 weight_decay=None, clip_norm=1.0, ddp=None):
         self.engine = engine
+        self.ddp = ddp                    # ddp.GradientAllReducer: one process per GPU, DataParallel semantics
         self.lambdas = (lambda_task, lambda_response, lambda_feature, lambda_bin, lambda_sparse)
         self.temperature = temperature
         self.opt_kind = {'AdamW': 0, 'Adam': 1, 'SGD': 2}[optimizer]
@@ -367,7 +376,18 @@ class AdaBinsTrainer(GraphedStep):
         self.exp_avg = torch.zeros_like(eng.flat_p)
         self.exp_avg_sq = torch.zeros_like(eng.flat_p)
         eng.step_counter = self.state
+        if self.ddp is not None:
+            # only the student's gradients (the suffix of the flat buffer) are exchanged: the teacher never trains
+            off = eng.train_offset
+            self._ddp_view = _GradView(eng.flat_g[off:])
+            self.ddp.attach(self._ddp_view)
+            eng.on_grad_ready = lambda lo: self._ddp_view.on_grad_ready(max(0, lo - off))
         self._ready = True
+
+    def enable_graph(self, after_steps=3):
+        if self.ddp is not None:
+            raise RuntimeError('the hipGraph step is not combined with the data-parallel reducer (host-side collectives)')
+        super().enable_graph(after_steps)
 
     def state_dict(self):
         """Optimizer state (flat Adam moments + step counter) for the checkpoint's 'optimizer_state_dict' entry."""
@@ -407,6 +427,13 @@ class AdaBinsTrainer(GraphedStep):
         lt, lr_, lf, lb, ls = self.lambdas
         K.distill_pix_stats(st.base, st.head.result, gt, te.final if has_t else None, m.max_depth, st.final,
                             eng.pix_stats, eng.workspace)
+        world = 1
+        if self.ddp is not None:
+            # DataParallel computes ONE loss on the gathered outputs (adabins_distillation_model.py:493-496): the pixel
+            # terms normalise by the global valid count (sum the statistics), the per-sample means become means over
+            # world x B samples (their weights / world here, gradients SUM-reduced below)
+            world = self.ddp.world_size
+            self.ddp.all_reduce_loss_stats(eng.pix_stats)
         B, HW = eng.B, st.logits.H * st.logits.W
         K.pool(st.logits.data, None, B, HW, m.n_bins, 1, 1.0 / HW, st.mean_logits, eng.workspace)
         if has_t:
@@ -414,15 +441,24 @@ class AdaBinsTrainer(GraphedStep):
             for i, (a, r) in enumerate(zip(st.feats, te.feats)):
                 K.pool(a.data, r.data, B, a.H * a.W, a.C, 3, 1.0, eng.feat_stats_buf[i], eng.workspace)
             eng.feat_stats = eng.feat_stats_buf
-            eng.feat_coef = [-lf / (5.0 * B * a.C) for a in st.feats]
+            eng.feat_coef = [-lf / (5.0 * B * a.C * world) for a in st.feats]
         else:
             eng.feat_stats, eng.feat_coef = None, None
         K.distill_small(st.mean_logits, te.mean_logits if has_t else None, st.centers, te.centers if has_t else None,
-                        eng.feat_stats_buf, [a.C for a in st.feats], eng.pix_stats, self.temperature, self.lambdas,
-                        eng.terms, st.dmean, st.dcent_extra)
+                        eng.feat_stats_buf, [a.C for a in st.feats], eng.pix_stats, self.temperature,
+                        (lt, lr_, lf / world, lb / world, ls), eng.terms, st.dmean, st.dcent_extra)
+        if self.ddp is not None:
+            # report the global terms: feature / KL / centre terms are means of the per-rank means
+            self.ddp.all_reduce_loss_stats(eng.terms[2:5])
+            eng.terms[2:5] /= world
+            eng.terms[6] = (lt * eng.terms[0] + lr_ * eng.terms[1] + lf * eng.terms[2] + lb * (eng.terms[3] + eng.terms[4])
+                            + ls * eng.terms[5])
+            self.ddp.begin_backward()
         K.distill_pix_grad(st.base, st.head.result, gt, te.final if has_t else None, m.max_depth, eng.pix_stats, lt,
                            lr_ if has_t else 0.0, ls, st.dbase, st.dres)
         eng.backward_student(st.dbase, st.dres, st.dmean, st.dcent_extra)
+        if self.ddp is not None:
+            self.ddp.finish()
         off = eng.train_offset
         p, g = eng.flat_p[off:], eng.flat_g[off:]
         if self.clip_norm is not None:

@@ -111,7 +111,7 @@ class BaseResidualTrainer(GraphedStep):
 
     def __init__(self, engine, lambda_recon=1.0, lambda_base=1.2, lambda_sparse=0.05, lowpass_kernel=16, use_l1=True,
                  use_silog=False, silog_lambda=0.5, optimizer='AdamW', lr=1e-4, betas=(0.9, 0.999), eps=1e-8,
-                 weight_decay=None, clip_norm=1.0):
+                 weight_decay=None, clip_norm=1.0, ddp=None):
         if not use_silog and not use_l1:
             raise NotImplementedError('the MSE reconstruction variant (use_l1=False, use_silog=False) is not implemented')
         self.engine = engine
@@ -121,7 +121,13 @@ class BaseResidualTrainer(GraphedStep):
         self.lr, self.betas, self.eps = float(lr), betas, float(eps)
         self.weight_decay = float((0.01 if optimizer == 'AdamW' else 0.0) if weight_decay is None else weight_decay)
         self.clip_norm = clip_norm
+        self.ddp = ddp                    # ddp.GradientAllReducer: one process per GPU, DataParallel semantics
         self._ready = False
+
+    def enable_graph(self, after_steps=3):
+        if self.ddp is not None:
+            raise RuntimeError('the hipGraph step is not combined with the data-parallel reducer (host-side collectives)')
+        super().enable_graph(after_steps)
 
     @classmethod
     def from_criterion(cls, engine, criterion, **kw):
@@ -150,6 +156,8 @@ class BaseResidualTrainer(GraphedStep):
         self.struct, self.gfinal = torch.empty_like(pred), torch.empty_like(pred)
         self.dbase, self.dres = torch.empty_like(pred), torch.empty_like(pred)
         self.exp_avg, self.exp_avg_sq = torch.zeros_like(eng.flat_p), torch.zeros_like(eng.flat_p)
+        if self.ddp is not None and not self._ready:
+            self.ddp.attach(eng)
         self._ready = True
 
     def state_dict(self):
@@ -173,12 +181,22 @@ class BaseResidualTrainer(GraphedStep):
         crit = 2                                               # Combined with one active weight = weighted L1 or SIlog
         l1w, sw = (0.0, self.lambda_recon) if self.use_silog else (self.lambda_recon, 0.0)
         K.loss_stats(final, gt, 1.0, 1, 1e-6, self.lstats, self.loss_ws)
+        if self.ddp is not None:          # one global-batch loss, as under DataParallel (base_residual_model.py:266-269)
+            self.ddp.all_reduce_loss_stats(self.lstats)
         K.loss_finish(final, gt, 1.0, 1, 1e-6, self.lstats, crit, l1w, sw, self.silog_lambda, self.recon, self.gfinal)
         K.baseres_stats(base, resid, self.struct, gt, self.recon, self.lambda_recon, self.lambda_base, self.lambda_sparse,
                         self.bstats, self.terms, eng.workspace)
+        if self.ddp is not None:
+            self.ddp.all_reduce_loss_stats(self.bstats)
+            n = self.bstats[0].clamp_min(1.0)
+            self.terms[1], self.terms[2] = self.bstats[1] / n, self.bstats[2] / n
+            self.terms[3] = self.terms[0] + self.lambda_base * self.terms[1] + self.lambda_sparse * self.terms[2]
+            self.ddp.begin_backward()
         K.baseres_grad(base, resid, self.struct, gt, self.gfinal, eng.module.max_depth, self.bstats, self.lambda_base,
                        self.lambda_sparse, self.dbase, self.dres)
         eng.backward_net(self.dbase, self.dres)
+        if self.ddp is not None:
+            self.ddp.finish()
         if self.clip_norm is not None:
             K.grad_norm(eng.flat_g, float(self.clip_norm), self.state, self.norm_ws)
         K.optimizer_step(eng.flat_p, eng.flat_g, self.exp_avg, self.exp_avg_sq, self.opt_kind, self.lr, self.betas[0],

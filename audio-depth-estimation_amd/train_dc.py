@@ -9,6 +9,10 @@ optimizer_state_dict, ...``; AdaBins: ``./results/<experiment>/``), its loop ord
 adabins_engine.AdaBinsTrainer).  Extra flags: ``--synthetic N`` (BatVision-shaped random items; no
 dataset is needed), ``--precision bf16|f32``.  wandb / visualisation plumbing is out of scope.
 Thin launchers with the reference's script names live next to this file.
+
+Multi-GPU: where the reference wraps the model in ``nn.DataParallel(gpu_ids)``, launch these with torchrun (one
+process per GPU, ``--batch_size`` is per GPU): ddp.GradientAllReducer reproduces DataParallel's single global-batch
+loss and SUM-reduces the gradients over RCCL; BatchNorm stays per replica; rank 0 prints and writes the checkpoints.
 """
 import argparse
 import math
@@ -73,17 +77,26 @@ def _common_flags(p, lr, batch):
     p.add_argument('--precision', type=str, default='bf16', choices=['bf16', 'f32'])
 
 
-def _device(args):
+def _dist():
+    """(rank, world, local_rank, reducer): torch.distributed from the torchrun environment, RCCL reducer when world > 1."""
+    from . import ddp as addp
+    rank, world, local = addp.init_from_env()
+    return rank, world, local, (addp.GradientAllReducer() if world > 1 else None)
+
+
+def _device(args, local=None):
     if not torch.cuda.is_available():
         raise RuntimeError('training runs on libadn HIP kernels: no HIP device is visible (there is no CPU path)')
     dev = torch.device(args.device)
-    if dev.index is None:
+    if local is not None and torch.cuda.device_count() > 1:
+        dev = torch.device('cuda', local)
+    elif dev.index is None:
         dev = torch.device('cuda', torch.cuda.current_device())
     torch.cuda.set_device(dev)
     return dev
 
 
-def _loaders(cfg, args, kind):
+def _loaders(cfg, args, kind, rank=0, world=1):
     if args.synthetic:
         S, md = cfg.dataset.images_size, cfg.dataset.max_depth
         train, val = SyntheticDepthItems(args.synthetic, S, md, kind), SyntheticDepthItems(max(1, args.synthetic // 4), S, md, kind)
@@ -101,9 +114,11 @@ def _loaders(cfg, args, kind):
             train = DS(cfg, cfg.dataset.annotation_file_train, use_image=img)
             val = DS(cfg, cfg.dataset.annotation_file_val, use_image=img)
         workers = args.num_workers
-    tl = DataLoader(train, batch_size=args.batch_size, shuffle=True, num_workers=workers, pin_memory=True, drop_last=True)
+    sampler = torch.utils.data.distributed.DistributedSampler(train, world, rank, shuffle=True) if world > 1 else None
+    tl = DataLoader(train, batch_size=args.batch_size, shuffle=sampler is None, sampler=sampler, num_workers=workers,
+                    pin_memory=True, drop_last=True)
     vl = DataLoader(val, batch_size=args.batch_size, shuffle=False, num_workers=workers, pin_memory=True)
-    return tl, vl
+    return tl, vl, sampler
 
 
 def _validate(model, loader, dev, forward):
@@ -121,14 +136,16 @@ def _validate(model, loader, dev, forward):
 
 
 def _run(args, cfg, model, trainer, kind, step, forward, exp, ckpt_root='checkpoints', ckpt_fmt='epoch_{:04d}.pth',
-         on_epoch=None):
-    dev = _device(args)
+         on_epoch=None, dist_info=(0, 1, None, None)):
+    rank, world, local, reducer = dist_info
+    dev = _device(args, local if world > 1 else None)
     torch.manual_seed(args.seed)
     model.compute_dtype = torch.bfloat16 if args.precision == 'bf16' else torch.float32
     model = model.to(dev).train()
-    tl, vl = _loaders(cfg, args, kind)
+    tl, vl, sampler = _loaders(cfg, args, kind, rank, world)
     ckpt_dir = os.path.join(ckpt_root, exp)
     os.makedirs(ckpt_dir, exist_ok=True)
+    say = print if rank == 0 else (lambda *a, **k: None)
     start = 0
     if args.checkpoints:
         path = os.path.join(ckpt_dir, ckpt_fmt.format(args.checkpoints))
@@ -138,30 +155,37 @@ def _run(args, cfg, model, trainer, kind, step, forward, exp, ckpt_root='checkpo
             if isinstance(ck.get('optimizer_state_dict'), dict) and 'exp_avg' in ck['optimizer_state_dict']:
                 trainer.load_state_dict(ck['optimizer_state_dict'], dev)
             start = ck['epoch']
-            print(f'Loaded checkpoint from epoch {start}')
+            say(f'Loaded checkpoint from epoch {start}')
+    if reducer is not None:                                  # replicate rank 0's weights once (DataParallel.replicate)
+        eng = model.engine()
+        eng.bind_parameters()
+        reducer.broadcast_parameters(eng.flat_p)
     best = float('inf')
     eta_min = getattr(args, 'eta_min', 0.0)
     for epoch in range(start, args.nb_epochs):
         trainer.lr = lr_at(epoch, args.scheduler, args.learning_rate, args.nb_epochs, eta_min)
         if on_epoch is not None:
             on_epoch(epoch + 1)
+        if sampler is not None:
+            sampler.set_epoch(epoch)
         t0, losses = time.time(), []
         for i, batch in enumerate(tl):
             loss = step(trainer, [t.to(dev, non_blocking=True) for t in batch])
             losses.append(loss.detach().clone())
             if (i + 1) % 10 == 0:
-                print(f'Epoch [{epoch + 1}/{args.nb_epochs}] Batch [{i + 1}/{len(tl)}] Loss: {losses[-1].item():.4f}')
+                say(f'Epoch [{epoch + 1}/{args.nb_epochs}] Batch [{i + 1}/{len(tl)}] Loss: {losses[-1].item():.4f}')
         train_loss = torch.stack(losses).mean().item() if losses else float('nan')
         errs = _validate(model, vl, dev, forward)
-        print(f'Epoch [{epoch + 1}/{args.nb_epochs}] train loss {train_loss:.4f}  val RMSE {errs["rmse"]:.4f} '
+        say(f'Epoch [{epoch + 1}/{args.nb_epochs}] train loss {train_loss:.4f}  val RMSE {errs["rmse"]:.4f} '
               f'ABS_REL {errs["abs_rel"]:.4f} Delta1 {errs["delta1"]:.4f}  lr {trainer.lr:.2e}  {time.time() - t0:.1f}s')
         state = {'epoch': epoch + 1, 'model_state_dict': model.state_dict(), 'optimizer_state_dict': trainer.state_dict(),
                  'train_loss': train_loss, 'val_errors': errs}
-        if (epoch + 1) % args.save_frequency == 0:
+        if (epoch + 1) % args.save_frequency == 0 and rank == 0:
             torch.save(state, os.path.join(ckpt_dir, ckpt_fmt.format(epoch + 1)))
         if errs['rmse'] < best:
             best = errs['rmse']
-            torch.save(dict(state, best_rmse=best), os.path.join(ckpt_dir, 'best_model.pth'))
+            if rank == 0:
+                torch.save(dict(state, best_rmse=best), os.path.join(ckpt_dir, 'best_model.pth'))
     return model
 
 
@@ -179,10 +203,11 @@ def main_rgb(argv=None):
     exp = args.experiment_name or f'rgb_depth_{args.dataset}_BS{args.batch_size}_Lr{args.learning_rate}_{args.optimizer}'
     model = create_rgb_depth_model(base_channels=args.base_channels, bilinear=args.bilinear,
                                    output_size=cfg.dataset.images_size, max_depth=cfg.dataset.max_depth)
+    di = _dist()
     trainer = FusedTrainer(model.engine(), 'DepthLoss', 1.0, 0.1, optimizer=args.optimizer, lr=args.learning_rate,
-                           weight_decay=args.weight_decay, clip_norm=None)
+                           weight_decay=args.weight_decay, clip_norm=None, ddp=di[3])
     step = lambda tr, b: tr.step(b[0], b[1])[0]
-    return _run(args, cfg, model, trainer, 'rgb', step, lambda m, b: m(b[0]), exp)
+    return _run(args, cfg, model, trainer, 'rgb', step, lambda m, b: m(b[0]), exp, dist_info=di)
 
 
 # ---- train_binaural_attention.py ---------------------------------------------------------------------------------------
@@ -212,11 +237,12 @@ def main_binaural(argv=None):
                                             attention_levels=args.attention_levels)
     if cfg.dataset.depth_norm:
         raise NotImplementedError('depth_norm with the binaural model (the head already outputs metres, reference :322-337)')
+    di = _dist()
     trainer = FusedTrainer(model.engine(), crit, l1w, sw, args.silog_lambda, max_depth=cfg.dataset.max_depth,
                            optimizer=args.optimizer, lr=args.learning_rate, weight_decay=args.weight_decay, clip_norm=None,
-                           mask_mode='gt0')
+                           mask_mode='gt0', ddp=di[3])
     step = lambda tr, b: tr.step(b[0], b[1])[0]
-    return _run(args, cfg, model, trainer, 'audio', step, lambda m, b: m(b[0]), exp)
+    return _run(args, cfg, model, trainer, 'audio', step, lambda m, b: m(b[0]), exp, dist_info=di)
 
 
 # ---- train_adabins_distillation.py -----------------------------------------------------------------------------------------
@@ -273,8 +299,9 @@ def main_adabins(argv=None):
         criterion = DistillationLoss(args.lambda_task, args.lambda_response, args.lambda_feature, args.lambda_bin,
                                      args.lambda_sparse, args.temperature)
     kind = 'audio' if (cfg.dataset.name == 'batvisionv1' and not args.synthetic) else 'both'
+    di = _dist()
     trainer = AdaBinsTrainer.from_criterion(model.engine(), criterion, optimizer=args.optimizer, lr=args.learning_rate,
-                                            clip_norm=1.0)
+                                            clip_norm=1.0, ddp=di[3])
     def on_epoch(epoch):                                     # criterion.set_epoch(epoch) at every epoch start (:437-438)
         if args.use_adaptive_loss:
             criterion.set_epoch(epoch)
@@ -286,7 +313,7 @@ def main_adabins(argv=None):
 
     fwd = lambda m, b: m(b[0], rgb=None, mode='inference')['audio']['final_depth']
     return _run(args, cfg, model, trainer, kind, step, fwd, exp, ckpt_root='results', ckpt_fmt='checkpoint_epoch_{:04d}.pth',
-                on_epoch=on_epoch)
+                on_epoch=on_epoch, dist_info=di)
 
 
 # ---- train_base_residual.py ------------------------------------------------------------------------------------------------
@@ -343,8 +370,9 @@ def main_base_residual(argv=None):
         criterion = BaseResidualLoss(lambda_recon=args.lambda_recon, lambda_base=args.lambda_base,
                                      lambda_sparse=args.lambda_sparse, lowpass_kernel=args.lowpass_kernel,
                                      use_silog=args.use_silog, silog_lambda=args.silog_lambda)
+    di = _dist()
     trainer = BaseResidualTrainer.from_criterion(model.engine(), criterion, optimizer=opt, lr=args.learning_rate,
-                                                 weight_decay=0.01 if opt == 'AdamW' else 0.0, clip_norm=1.0)
+                                                 weight_decay=0.01 if opt == 'AdamW' else 0.0, clip_norm=1.0, ddp=di[3])
 
     def on_epoch(epoch):
         if args.use_adaptive_loss:
@@ -353,4 +381,4 @@ def main_base_residual(argv=None):
 
     step = lambda tr, b: tr.step(b[0], b[1])[0]
     return _run(args, cfg, model, trainer, 'audio', step, lambda m, b: m(b[0])[2], args.experiment_name,
-                ckpt_fmt='checkpoint_{}.pth', on_epoch=on_epoch)
+                ckpt_fmt='checkpoint_{}.pth', on_epoch=on_epoch, dist_info=di)

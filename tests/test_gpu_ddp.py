@@ -130,3 +130,114 @@ def test_two_ranks_one_gpu(kind):
     assert abs(float(tr.loss) - l0) <= 1e-6 * abs(l0)
     # BN running statistics are per replica (rank 0 = shard 0): parameters (incl. them) must agree with engine a
     assert float(np.abs(got - want).max()) <= 1e-6 + 0.02 * tr.lr
+
+
+# ---- AdaBins distillation / Base+Residual trainers (the reference wraps both in nn.DataParallel when given gpu_ids:
+# adabins_distillation_model.py:493-496, base_residual_model.py:266-269) ---------------------------------------------
+def _make2(kind, ddp=None):
+    torch.manual_seed(0)
+    if kind == 'adabins':
+        from audio_depth_estimation_amd.adabins_engine import AdaBinsTrainer
+        from audio_depth_estimation_amd.models.adabins_distillation_model import AdaBinsDistillationModel
+        m = AdaBinsDistillationModel(16, 64, 32, 30.0)
+        m.compute_dtype = torch.float32
+        m = m.to('cuda').train()
+        tr = AdaBinsTrainer(m.engine(), lr=1e-3, ddp=ddp)
+    else:
+        from audio_depth_estimation_amd.base_residual_engine import BaseResidualTrainer
+        from audio_depth_estimation_amd.models.base_residual_model import BaseResidualDepthNet
+        m = BaseResidualDepthNet(2, 64, True, 32, 30.0)
+        m.compute_dtype = torch.float32
+        m = m.to('cuda').train()
+        tr = BaseResidualTrainer(m.engine(), use_silog=True, lr=1e-3, ddp=ddp)
+    m.engine().bind_parameters()
+    return m, tr
+
+
+def _shard2(seed, B=2, S=32):
+    g = torch.Generator().manual_seed(200 + seed)
+    audio, rgb = torch.rand(B, 2, S, S, generator=g), torch.rand(B, 3, S, S, generator=g)
+    gt = 30 * torch.rand(B, 1, S, S, generator=g)
+    gt[gt < (3 + 6 * seed)] = 0
+    return audio.to('cuda'), rgb.to('cuda'), gt.to('cuda')
+
+
+def _step2(kind, tr, shard):
+    audio, rgb, gt = shard
+    loss, terms = tr.step(audio, rgb, gt) if kind == 'adabins' else tr.step(audio, gt)
+    return float(loss), terms.detach().cpu().clone()
+
+
+def _worker2(rank, world, port, kind, same, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from audio_depth_estimation_amd.ddp import GradientAllReducer
+        red = GradientAllReducer(bucket_bytes=1 << 20)
+        model, tr = _make2(kind, red)
+        red.broadcast_parameters(model.engine().flat_p)
+        shard = _shard2(0 if same else rank)
+        loss, terms = _step2(kind, tr, shard)
+        first = model.engine().flat_p.detach().cpu().clone()
+        for _ in range(2):
+            _step2(kind, tr, shard)
+        torch.cuda.synchronize()
+        out.put((rank, loss, terms.numpy().tobytes(), first.numpy().tobytes(),
+                 model.engine().flat_p.detach().cpu().numpy().tobytes()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn2(kind, same):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker2, args=(r, 2, port, kind, same, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize('kind', ['adabins', 'baseres'])
+def test_two_ranks_distillation_trainers(kind):
+    import numpy as np
+    # (1) different shards: one global loss, replicas stay bit-identical over three steps
+    (_, l0, t0, _, p0), (_, l1, t1, _, p1) = _spawn2(kind, same=False)
+    assert l0 == l1 and t0 == t1
+    assert p0 == p1
+    # (2) both ranks on the SAME shard: the global-batch loss and the SUM-reduced gradient equal the single-process
+    #     ones (every normaliser doubles), so the first step must match a plain trainer step on that shard
+    (_, l0, t0, f0, _), _ = _spawn2(kind, same=True)
+    model, tr = _make2(kind)
+    loss, terms = _step2(kind, tr, _shard2(0))
+    want = model.engine().flat_p.detach().cpu().numpy()
+    got = np.frombuffer(f0, dtype=np.float32)
+    assert abs(loss - l0) <= 1e-5 * abs(loss)
+    tg, tw = np.frombuffer(t0, dtype=np.float32), terms.numpy()
+    nt = 7 if kind == 'adabins' else 4                # (AdaBins terms[7] is the valid-pixel count: global = 2x)
+    np.testing.assert_allclose(tg[:nt], tw[:nt], rtol=1e-5, atol=1e-7)
+    if kind == 'adabins':
+        assert tg[7] == 2 * tw[7]
+    assert float(np.abs(got - want).max()) <= 1e-6 + 0.02 * tr.lr
+
+
+def test_torchrun_entry_point_two_ranks(tmp_path):
+    """The train_adabins_distillation counterpart under torchrun (2 ranks on one GPU, gloo): rank 0 writes the
+    checkpoint, each rank takes its half of the 8 synthetic items (2 fused steps of batch 2 per rank)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ADN_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0',
+               PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', str(_free_port()), '-m', 'audio_depth_estimation_amd.train_adabins_distillation',
+           '--synthetic', '8', '--batch_size', '2', '--nb_epochs', '1', '--experiment_name', 'ddp', '--precision', 'f32']
+    r = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    ck = torch.load(os.path.join(tmp_path, 'results', 'ddp', 'best_model.pth'), map_location='cpu')
+    assert ck['epoch'] == 1 and ck['optimizer_state_dict']['step'] == 2
+    assert all(torch.isfinite(v).all() for v in ck['model_state_dict'].values() if v.is_floating_point())
