@@ -71,36 +71,37 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* src, T* 
   }
 }
 
-// every layer's T2 pack in one launch: blockIdx -> layer by a linear scan of the (tiny) table
+// every layer's T2 pack in one launch: blockIdx -> layer by a linear scan of the (tiny) table.  64 x 64 tiles: 256-byte
+// reads of the f32 master rows, 128-byte writes of the bf16 pack rows.
 template <typename T>
 __global__ __launch_bounds__(256) void pack_t2_multi_kernel(const float* flat_master, const int64_t* table, int layers,
                                                             T* t2_base) {
-  __shared__ float tile[32][33];
+  __shared__ float tile[64][65];
   int l = 0;
   while (l + 1 < layers && (int64_t)blockIdx.x >= table[(l + 1) * 5 + 4]) ++l;
   const float* master = flat_master + table[l * 5 + 0];
   const int X = (int)table[l * 5 + 1], Y = (int)table[l * 5 + 2];
   T* t2 = t2_base + table[l * 5 + 3];
   const int local = (int)((int64_t)blockIdx.x - table[l * 5 + 4]);
-  const int tiles_xy = ((X + 31) / 32) * ((Y + 31) / 32);
+  const int tiles_y = (Y + 63) / 64;
+  const int tiles_xy = ((X + 63) / 64) * tiles_y;
   const int tap = local / tiles_xy, txy = local % tiles_xy;
   const int kh = tap >> 2, kw = tap & 3;
   const int ph = (kh & 1) ? 0 : 1, ty = (kh == 3 || kh == 2) ? 1 : 0;
   const int pw = (kw & 1) ? 0 : 1, tx = (kw == 3 || kw == 2) ? 1 : 0;
   const int phase = ph * 2 + pw, t = ty * 2 + tx;
-  const int tiles_y = (Y + 31) / 32;
-  const int x0 = (txy / tiles_y) * 32, y0 = (txy % tiles_y) * 32;
-  const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+  const int x0 = (txy / tiles_y) * 64, y0 = (txy % tiles_y) * 64;
+  const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int x = x0 + ly + 8 * r, y = y0 + lx;
-    tile[ly + 8 * r][lx] = (x < X && y < Y) ? master[((int64_t)x * 16 + tap) * Y + y] : 0.f;
+  for (int r = 0; r < 16; ++r) {
+    const int x = x0 + ly + 4 * r, y = y0 + lx;
+    tile[ly + 4 * r][lx] = (x < X && y < Y) ? master[((int64_t)x * 16 + tap) * Y + y] : 0.f;
   }
   __syncthreads();
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int y = y0 + ly + 8 * r, x = x0 + lx;
-    if (x < X && y < Y) ElemTraits<T>::store(t2 + (((int64_t)phase * Y + y) * 4 + t) * X + x, tile[lx][ly + 8 * r]);
+  for (int r = 0; r < 16; ++r) {
+    const int y = y0 + ly + 4 * r, x = x0 + lx;
+    if (x < X && y < Y) ElemTraits<T>::store(t2 + (((int64_t)phase * Y + y) * 4 + t) * X + x, tile[lx][ly + 4 * r]);
   }
 }
 template <typename T>

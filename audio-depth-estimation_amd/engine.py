@@ -171,7 +171,7 @@ class UNetEngine(FlatParamEngine):
                 rows.append([self.offset[id(w)], X, Y, t2_off, blk])
                 lv[wk + '_t2_off'] = t2_off
                 t2_off += 16 * X * Y
-                blk += ((X + 31) // 32) * ((Y + 31) // 32) * 16
+                blk += ((X + 63) // 64) * ((Y + 63) // 64) * 16
         self.t2_all = torch.empty(t2_off, dtype=T, device=dev)
         for lv in self.levels:
             for wk in ('down', 'up'):

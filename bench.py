@@ -15,6 +15,7 @@ Rank 0 prints ONE JSON line; it also carries
                 on a bounded sample (rank 0, N=1 only).
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -62,7 +63,8 @@ def cpu_baseline(B, steps, warmup):
     torch.set_num_threads(cores)
     cfg = SimpleNamespace(dataset=SimpleNamespace(depth_norm=False, max_depth=30.0))
     torch.manual_seed(0)
-    model = define_G(cfg, 2, 1, 64, 'unet_256')
+    with contextlib.redirect_stdout(sys.stderr):      # define_G prints its init banner like the reference: keep stdout = the JSON line
+        model = define_G(cfg, 2, 1, 64, 'unet_256')
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     pkeys = unet_oracle.param_keys(8)
     params = [sd[k].requires_grad_(True) for k in pkeys]
@@ -117,7 +119,8 @@ def main():
 
     cfg = SimpleNamespace(dataset=SimpleNamespace(depth_norm=False, max_depth=30.0))
     torch.manual_seed(0)
-    model = define_G(cfg, 2, 1, 64, 'unet_256')
+    with contextlib.redirect_stdout(sys.stderr):      # define_G prints its init banner like the reference: keep stdout = the JSON line
+        model = define_G(cfg, 2, 1, 64, 'unet_256')
     model.compute_dtype = dtype
     model = model.to(device).train()
     reducer = addp.GradientAllReducer() if world > 1 else None

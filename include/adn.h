@@ -388,7 +388,7 @@ int adn_optimizer_step(float* params, const float* grads, float* exp_avg, float*
                        void* stream);
 /* All T2 (phase-split) weight packs of a network in ONE launch.  table (device, int64 [L][5]):
  * master offset (floats) into flat_master, X, Y, t2 offset (elements) into t2_base, first block index;
- * total_blocks = sum over layers of ceil(X/32)*ceil(Y/32)*16. */
+ * total_blocks = sum over layers of ceil(X/64)*ceil(Y/64)*16. */
 int adn_pack_t2_multi(const float* flat_master, const int64_t* table, int32_t layers,
                       int64_t total_blocks, int32_t dtype, void* t2_base, void* stream);
 
