@@ -531,7 +531,8 @@ bool make_plan(const AdnIgemmDesc* d, Plan* pl) {
   //  prologue/epilogue better: measured 685 vs 621 TFLOP/s on L1 forward)
   const bool fills256 = adn_cdiv(msmall, 256) * (d->N / pl->bn) * pl->phases >= 256;
   pl->bm = (fills256 && (pl->bn == 64 || taps * Cin / bk >= 32)) ? 256 : 128;
-  if (const char* e = getenv("ADN_IGEMM_BM")) pl->bm = atoi(e) == 256 ? 256 : 128;   // tuning knob
+  if (const char* e = getenv("ADN_IGEMM_BM")) pl->bm = atoi(e) == 256 ? 256 : 128;   // tuning knobs
+  if (const char* e = getenv("ADN_IGEMM_BN")) pl->bn = (atoi(e) == 128 && d->N % 128 == 0) ? 128 : 64;
   pl->tiles_m = (int)adn_cdiv(msmall, pl->bm);
   pl->tiles_n = d->N / pl->bn;
   pl->kpt = 0;

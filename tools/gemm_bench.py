@@ -59,12 +59,15 @@ def main():
     ap.add_argument('--bwd', action='store_true')
     ap.add_argument('--b2', type=int, default=8)
     ap.add_argument('--s1', action='store_true', help='stride-1 3x3 shapes of the DoubleConv nets instead')
+    ap.add_argument('--edge', action='store_true', help='thin outermost layers of unet_256 with their real epilogues')
     args = ap.parse_args()
     torch.manual_seed(0)
     if args.s1:
         return s1_main(args)
     if args.attn:
         return attn_main(args)
+    if args.edge:
+        return edge_main(args)
     for name, geom, Hs, C0, C1, N in IGEMM:
         if args.only and args.only not in name:
             continue
@@ -94,6 +97,37 @@ def main():
         t = timeit(fn, args.iters)
         fl = 2.0 * B * Hs * Hs * (R0 + R1) * 16 * C
         print(f'{name:10s} M={B*Hs*Hs:7d} R={R0+R1:4d} C={C:4d}        {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF/s (incl. slab sum)', flush=True)
+
+
+def edge_main(args):
+    """D0 dgrad: the gradient of the 1-channel output (padded to 8) through the outermost ConvT, split into the skip
+    half (ReLU mask) and the up half (ReLU mask + BN-backward statistics): K = 128, N = 128, M = 524288 -- all epilogue."""
+    Hs = 128
+    dz = torch.randn(B, 2 * Hs, 2 * Hs, 8, device=DEV).to(T)
+    w = (torch.randn(128 * 16 * 8, device=DEV) * 0.05).to(T)
+    mk = lambda: torch.randn(B, Hs, Hs, 64, device=DEV).to(T)
+    Gd, Gu, rd, ru, zu = mk(), mk(), mk(), mk(), mk()
+    mean, istd = torch.zeros(64, device=DEV), torch.ones(64, device=DEV)
+    P, wsb = K.igemm_query(T, 0, B, Hs, Hs, 8, 0, 128, [64, 64])
+    ws = torch.empty(max(wsb, 16) // 4, device=DEV)
+    part = torch.empty(P * 2 * 64, device=DEV)
+    segs = [K.Seg(64, out0=Gd, ref=rd, slope=0.0),
+            K.Seg(64, out0=Gu, ref=ru, slope=0.0, z=zu, mean=mean, istd=istd, partials=part)]
+    fn = lambda: K.igemm(T, 0, B, Hs, Hs, dz, None, w, 128, 3, segs, ws)
+    t = timeit(fn, args.iters)
+    byts = B * Hs * Hs * 64 * 2 * 5 + dz.numel() * 2
+    print(f'D0_dgrad_bwd M={B*Hs*Hs} N=128 K=128  {t*1e6:8.1f} us  {byts/t/1e12:6.2f} TB/s (algorithmic bytes)', flush=True)
+    # L0 forward: 2 -> 64 channels (input padded to 8), K = 128, N = 64, raw output + leaky copy
+    x = torch.randn(B, 2 * Hs, 2 * Hs, 8, device=DEV).to(T)
+    w0 = (torch.randn(64 * 16 * 8, device=DEV) * 0.05).to(T)
+    o0, o1 = mk(), mk()
+    P, wsb = K.igemm_query(T, 0, B, Hs, Hs, 8, 0, 64, [64])
+    ws = torch.empty(max(wsb, 16) // 4, device=DEV)
+    sc, sh = torch.ones(64, device=DEV), torch.zeros(64, device=DEV)
+    fn = lambda: K.igemm(T, 0, B, Hs, Hs, x, None, w0, 64, 2, [K.Seg(64, out0=o0, out1=o1, scale=sc, shift=sh, slope=0.2)], ws)
+    t = timeit(fn, args.iters)
+    byts = B * Hs * Hs * 64 * 2 * 2 + x.numel() * 2
+    print(f'L0_fwd_act   M={B*Hs*Hs} N= 64 K=128  {t*1e6:8.1f} us  {byts/t/1e12:6.2f} TB/s (algorithmic bytes)', flush=True)
 
 
 def s1_main(args):
