@@ -546,6 +546,10 @@ bool make_plan(const AdnIgemmDesc* d, Plan* pl) {
     if (ns > 64) ns = 64;
     if (ns < 1) ns = 1;
   }
+  if (const char* e = getenv("ADN_IGEMM_NS")) {             // tuning knob: cap on the split count
+    const int cap = atoi(e);
+    if (cap >= 1 && ns > cap) ns = cap;
+  }
   pl->nsplit = ns;
   pl->rb = reduce_rows(pl->mout, d->N);
   if (ns > 1) {

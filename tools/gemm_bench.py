@@ -24,6 +24,11 @@ IGEMM = [
     ('D1_dgrad', 0, 64, 64, 0, 256), ('D2_dgrad', 0, 32, 128, 0, 512), ('L2_dgrad', 1, 32, 256, 0, 128),
     ('L1_dgrad', 1, 64, 128, 0, 64),
 ]
+# the deep (small-M, split-K) layers: --deep
+DEEP = [('L5_fwd', 0, 4, 512, 0, 512), ('L6_fwd', 0, 2, 512, 0, 512), ('L7_fwd', 0, 1, 512, 0, 512),
+        ('D7_fwd', 1, 1, 512, 0, 512), ('D6_fwd', 1, 2, 512, 512, 512), ('D5_fwd', 1, 4, 512, 512, 512),
+        ('D4_fwd', 1, 8, 512, 512, 512), ('L4_fwd', 0, 8, 512, 0, 512),
+        ('D5_dgrad', 0, 4, 512, 0, 1024), ('D6_dgrad', 0, 2, 512, 0, 1024), ('L5_dgrad', 1, 4, 512, 0, 512)]
 # name, Hs, R0, R1, C
 WGRAD = [('L1_wgrad', 64, 128, 0, 64), ('L2_wgrad', 32, 256, 0, 128), ('L3_wgrad', 16, 512, 0, 256),
          ('D1_wgrad', 64, 128, 128, 64), ('D2_wgrad', 32, 256, 256, 128), ('D3_wgrad', 16, 512, 512, 256)]
@@ -59,6 +64,7 @@ def main():
     ap.add_argument('--bwd', action='store_true')
     ap.add_argument('--b2', type=int, default=8)
     ap.add_argument('--s1', action='store_true', help='stride-1 3x3 shapes of the DoubleConv nets instead')
+    ap.add_argument('--deep', action='store_true', help='the small-M split-K layers of unet_256 instead')
     ap.add_argument('--edge', action='store_true', help='thin outermost layers of unet_256 with their real epilogues')
     args = ap.parse_args()
     torch.manual_seed(0)
@@ -68,7 +74,7 @@ def main():
         return attn_main(args)
     if args.edge:
         return edge_main(args)
-    for name, geom, Hs, C0, C1, N in IGEMM:
+    for name, geom, Hs, C0, C1, N in (DEEP if args.deep else IGEMM):
         if args.only and args.only not in name:
             continue
         hin = 2 * Hs if geom == 0 else Hs
@@ -85,7 +91,7 @@ def main():
         t = timeit(fn, args.iters)
         fl = 2.0 * B * Hs * Hs * N * 16 * (C0 + C1)
         print(f'{name:10s} M={B*Hs*Hs*(1 if geom == 0 else 4):7d} N={N:4d} K={taps*(C0+C1):5d}  {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF/s', flush=True)
-    for name, Hs, R0, R1, C in WGRAD:
+    for name, Hs, R0, R1, C in ([] if args.deep else WGRAD):
         if args.only and args.only not in name:
             continue
         p0 = torch.randn(B, Hs, Hs, R0, device=DEV).to(T)
