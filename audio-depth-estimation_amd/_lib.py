@@ -93,6 +93,7 @@ _PROTOS = {
     'adn_maxpool2_bwd': (C.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     'adn_upsample2x_fwd': (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     'adn_upsample2x_bwd': (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    'adn_pixel_shuffle2': (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     'adn_relu_bwd_stats_num_partials': (c_int64, [c_int64, c_int32]),
     'adn_relu_bwd_stats': (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     'adn_head1x1_fwd': (C.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p]),

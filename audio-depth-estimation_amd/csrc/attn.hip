@@ -17,7 +17,8 @@
 
 namespace {
 
-constexpr int kMaxDv = 512;
+constexpr int kMaxDv = 1024;       // value channels (16 per lane)
+constexpr int kMaxDqk = 128;       // query / key channels (2 per lane)
 constexpr int kWaves = 4;
 
 struct AttnParams {
@@ -38,14 +39,15 @@ __device__ __forceinline__ float ldg(const void* base, int64_t idx) {
 // ---- forward: one wave per query ---------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void attn_fwd_generic(AttnParams p) {
-  __shared__ float qs[kWaves][64];
+  __shared__ float qs[kWaves][kMaxDqk];
   __shared__ float ps[kWaves][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b = blockIdx.y;
   const int i = blockIdx.x * kWaves + wave;
   const int kb = (b + p.kv_shift) % p.B2;
   const bool live = i < p.N;
-  if (live && lane < p.dqk) qs[wave][lane] = ldg<T>(p.q, ((int64_t)b * p.N + i) * p.ld_q + lane);
+  if (live)
+    for (int d = lane; d < p.dqk; d += 64) qs[wave][d] = ldg<T>(p.q, ((int64_t)b * p.N + i) * p.ld_q + d);
   __syncthreads();
   float m = -INFINITY, l = 0.f;
   float o[kMaxDv / 64];
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(256) void attn_rowdot(const void* a, int lda, const
 // ---- backward, dQ: one wave per query --------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd_dq_generic(AttnParams p) {
-  __shared__ float qs[kWaves][64];
+  __shared__ float qs[kWaves][kMaxDqk];
   __shared__ float dos[kWaves][kMaxDv];
   __shared__ float dss[kWaves][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -120,13 +122,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_generic(AttnParams p) {
   float lse = 0.f, Di = 0.f;
   if (live) {
     const int64_t row = (int64_t)b * p.N + i;
-    if (lane < p.dqk) qs[wave][lane] = ldg<T>(p.q, row * p.ld_q + lane);
+    for (int d = lane; d < p.dqk; d += 64) qs[wave][d] = ldg<T>(p.q, row * p.ld_q + d);
     for (int c = lane; c < p.dvv; c += 64) dos[wave][c] = ldg<T>(p.dout, row * p.ld_do + c);
     lse = p.lse[row];
     Di = p.dsum[row];
   }
   __syncthreads();
-  float dq = 0.f;
+  float dq[kMaxDqk / 64] = {0.f, 0.f};
   for (int j0 = 0; j0 < p.N; j0 += 64) {
     const int j = j0 + lane;
     float ds = 0.f;
@@ -142,21 +144,32 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_generic(AttnParams p) {
     }
     dss[wave][lane] = ds;
     __syncthreads();
-    if (live && lane < p.dqk) {
+    if (live) {
       const int jn = p.N - j0 < 64 ? p.N - j0 : 64;
-      const int64_t kbse = ((int64_t)kb * p.N + j0) * p.ld_k + lane;
-      for (int jj = 0; jj < jn; ++jj) dq += dss[wave][jj] * ldg<T>(p.k, kbse + (int64_t)jj * p.ld_k);
+#pragma unroll
+      for (int u = 0; u < kMaxDqk / 64; ++u) {
+        const int d = lane + 64 * u;
+        if (d < p.dqk) {
+          const int64_t kbse = ((int64_t)kb * p.N + j0) * p.ld_k + d;
+          float acc = dq[u];
+          for (int jj = 0; jj < jn; ++jj) acc += dss[wave][jj] * ldg<T>(p.k, kbse + (int64_t)jj * p.ld_k);
+          dq[u] = acc;
+        }
+      }
     }
     __syncthreads();
   }
-  if (live && lane < p.dqk)
-    ElemTraits<T>::store(reinterpret_cast<T*>(p.dq) + ((int64_t)b * p.N + i) * p.ld_dq + lane, dq);
+  if (live)
+#pragma unroll
+    for (int u = 0; u < kMaxDqk / 64; ++u)
+      if (lane + 64 * u < p.dqk)
+        ElemTraits<T>::store(reinterpret_cast<T*>(p.dq) + ((int64_t)b * p.N + i) * p.ld_dq + lane + 64 * u, dq[u]);
 }
 
 // ---- backward, dK / dV: one wave per key -------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_generic(AttnParams p) {
-  __shared__ float ks[kWaves][64];
+  __shared__ float ks[kWaves][kMaxDqk];
   __shared__ float vs[kWaves][kMaxDv];
   __shared__ float pss[kWaves][64];
   __shared__ float dss[kWaves][64];
@@ -167,11 +180,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_generic(AttnParams p) {
   const bool live = j < p.N;
   if (live) {
     const int64_t row = (int64_t)kb * p.N + j;
-    if (lane < p.dqk) ks[wave][lane] = ldg<T>(p.k, row * p.ld_k + lane);
+    for (int d = lane; d < p.dqk; d += 64) ks[wave][d] = ldg<T>(p.k, row * p.ld_k + d);
     for (int c = lane; c < p.dvv; c += 64) vs[wave][c] = ldg<T>(p.v, row * p.ld_v + c);
   }
   __syncthreads();
-  float dk = 0.f;
+  float dk[kMaxDqk / 64] = {0.f, 0.f};
   float dvacc[kMaxDv / 64];
 #pragma unroll
   for (int u = 0; u < kMaxDv / 64; ++u) dvacc[u] = 0.f;
@@ -202,8 +215,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_generic(AttnParams p) {
           dvacc[u] = acc;
         }
       }
-      if (lane < p.dqk)
-        for (int ii = 0; ii < in; ++ii) dk += dss[wave][ii] * ldg<T>(p.q, (rb + ii) * p.ld_q + lane);
+#pragma unroll
+      for (int u = 0; u < kMaxDqk / 64; ++u) {
+        const int d = lane + 64 * u;
+        if (d < p.dqk) {
+          float acc = dk[u];
+          for (int ii = 0; ii < in; ++ii) acc += dss[wave][ii] * ldg<T>(p.q, (rb + ii) * p.ld_q + d);
+          dk[u] = acc;
+        }
+      }
     }
     __syncthreads();
   }
@@ -213,7 +233,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_generic(AttnParams p) {
       const int c = lane + 64 * u;
       if (c < p.dvv) ElemTraits<T>::store(reinterpret_cast<T*>(p.dv) + row * p.ld_dv + c, dvacc[u]);
     }
-    if (lane < p.dqk) ElemTraits<T>::store(reinterpret_cast<T*>(p.dk) + row * p.ld_dk + lane, dk);
+#pragma unroll
+    for (int u = 0; u < kMaxDqk / 64; ++u)
+      if (lane + 64 * u < p.dqk) ElemTraits<T>::store(reinterpret_cast<T*>(p.dk) + row * p.ld_dk + lane + 64 * u, dk[u]);
   }
 }
 
@@ -319,7 +341,8 @@ int avalidate(const AdnAttnDesc* d, bool bwd) {
   ADN_CHECK_ARG(d != nullptr, "adn_attn: null descriptor");
   ADN_CHECK_ARG(d->dtype == ADN_F32 || d->dtype == ADN_BF16, "adn_attn: bad dtype %d", d->dtype);
   ADN_CHECK_ARG(d->B2 > 0 && d->N > 0 && d->dqk > 0 && d->dv > 0, "adn_attn: bad shape");
-  ADN_CHECK_ARG(d->dqk <= 64 && d->dv <= kMaxDv, "adn_attn: head dims %d/%d exceed 64/%d", d->dqk, d->dv, kMaxDv);
+  ADN_CHECK_ARG(d->dqk <= kMaxDqk && d->dv <= kMaxDv, "adn_attn: head dims %d/%d exceed %d/%d", d->dqk, d->dv, kMaxDqk,
+                kMaxDv);
   ADN_CHECK_ARG(d->kv_shift >= 0 && d->kv_shift < d->B2, "adn_attn: bad kv_shift %d", d->kv_shift);
   ADN_CHECK_ARG(d->q && d->k && d->v && d->o && d->lse, "adn_attn: null operand");
   ADN_CHECK_ARG(d->ld_q >= d->dqk && d->ld_k >= d->dqk && d->ld_v >= d->dv && d->ld_o >= d->dv, "adn_attn: bad strides");

@@ -52,6 +52,31 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* src, T* dst,
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// ConvTranspose2d(k 2, s 2) of the bilinear=False `Up` (binaural_attention_model.py:64-67) is a 1x1 GEMM to
+// [B][H][W][4][C] (tap t = 2i + j, then channel) followed by this pixel shuffle:
+//   spatial[b][2y + i][2x + j][c] = packed[b][y][x][2i + j][c]        (inverse: the gather of the gradient)
+template <typename T, int V>
+__global__ __launch_bounds__(256) void pixel_shuffle2_kernel(const T* src, T* dst, int B, int H, int W, int C, int inverse) {
+  const int ncg = C / V;
+  const int64_t work = (int64_t)B * H * W * 4 * ncg;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < work; idx += (int64_t)gridDim.x * 256) {
+    const int cg = (int)(idx % ncg);
+    int64_t r = idx / ncg;
+    const int t = (int)(r & 3);
+    r >>= 2;
+    const int x = (int)(r % W);
+    r /= W;
+    const int y = (int)(r % H);
+    const int b = (int)(r / H);
+    const int64_t packed = ((((int64_t)b * H + y) * W + x) * 4 + t) * C + cg * V;
+    const int64_t spatial = (((int64_t)b * 2 * H + 2 * y + (t >> 1)) * 2 * W + 2 * x + (t & 1)) * C + cg * V;
+    float v[V];
+    loadv<T, V>(src, inverse ? spatial : packed, v);
+    storev<T, V>(dst, inverse ? packed : spatial, v);
+  }
+}
+
 // Backward: the gradient of a window goes to its FIRST maximum in scan order (strict >), as torch does.
 // gsrc (+)= routed gdst; pixels of a trailing odd row/column get 0.
 template <typename T, int V>
@@ -580,6 +605,25 @@ extern "C" int adn_upsample2x_bwd(const void* gdst, void* gsrc, int32_t B, int32
     auto gs = reinterpret_cast<float*>(gsrc);
     ADN_DISPATCH_V(upsample2x_bwd_kernel, float, dim3(blocks_for(work)), st, gd, gs, B, Hi, Wi, Ho, Wo, padT, padL, C,
                     accumulate);
+  }
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}
+
+extern "C" int adn_pixel_shuffle2(const void* src, void* dst, int32_t B, int32_t H, int32_t W, int32_t C, int32_t inverse,
+                                  int32_t dtype, void* stream) {
+  ADN_CHECK_ARG(src && dst && B > 0 && H > 0 && W > 0 && C > 0, "adn_pixel_shuffle2: bad arguments");
+  ADN_CHECK_ARG(dtype == ADN_F32 || dtype == ADN_BF16, "adn_pixel_shuffle2: bad dtype %d", dtype);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int64_t work = (int64_t)B * H * W * 4 * ((C & 7) == 0 ? C / 8 : C);
+  if (dtype == ADN_BF16) {
+    auto sp = reinterpret_cast<const uint16_t*>(src);
+    auto dp = reinterpret_cast<uint16_t*>(dst);
+    ADN_DISPATCH_V(pixel_shuffle2_kernel, uint16_t, dim3(blocks_for(work)), st, sp, dp, B, H, W, C, inverse);
+  } else {
+    auto sp = reinterpret_cast<const float*>(src);
+    auto dp = reinterpret_cast<float*>(dst);
+    ADN_DISPATCH_V(pixel_shuffle2_kernel, float, dim3(blocks_for(work)), st, sp, dp, B, H, W, C, inverse);
   }
   ADN_CHECK_LAUNCH();
   return ADN_OK;

@@ -291,6 +291,72 @@ class Upsample2x(Op):
         self.src.written = True
 
 
+class ConvT2x2(Op):
+    """nn.ConvTranspose2d(Cin, Cin // 2, kernel_size=2, stride=2) of ``Up(bilinear=False)``: non-overlapping taps, so
+    it is a 1x1 GEMM [pixels, Cin] x [Cin, 4 Cout] into a tap-major buffer + a pixel shuffle; the backward is the
+    inverse shuffle, a 1x1 input-gradient GEMM and a 1x1 weight-gradient GEMM.  The flat parameter storage of a 4-D
+    weight is [dim0][kh][kw][dim1] (flat.py), i.e. [Cin][tap][Cout] here: it IS the GEMM's [K = Cin][N = 4 Cout]
+    operand in the buffer's tap-major column order, and the weight-gradient GEMM writes the gradient slice in place."""
+
+    def __init__(self, src, convt, out):
+        assert convt.kernel_size == (2, 2) and convt.stride == (2, 2) and convt.padding == (0, 0)
+        assert convt.output_padding == (0, 0) and convt.groups == 1 and convt.dilation == (1, 1)
+        self.src, self.convt, self.out = src, convt, out
+        if (out.H, out.W) != (2 * src.H, 2 * src.W):
+            raise NotImplementedError('ConvTranspose2d upsampling followed by F.pad (odd skip sizes) is not implemented')
+        out.producer = self
+        src.consumers.append(self)
+
+    def prepare(self, eng):
+        T, dev, B = eng.dtype, eng.dev, eng.B
+        s, o = self.src, self.out
+        cin, cout = self.convt.weight.shape[0], self.convt.weight.shape[1]
+        assert s.C == cin and o.C == cout and not hasattr(s, 'C_real')
+        self.cin, self.cout, self.n4 = cin, cout, 4 * cout
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.tmp = torch.empty(B, s.H, s.W, self.n4, dtype=T, device=dev)            # forward GEMM output / its gradient
+        self.w_fwd = torch.zeros(self.n4, K.s1_row_stride(T, 1, cin), dtype=T, device=dev)
+        self.w_dg = torch.zeros(cin, K.s1_row_stride(T, 1, self.n4), dtype=T, device=dev) if s.needs_grad else None
+        self.bias4 = torch.zeros(self.n4, **f32) if self.convt.bias is not None else None
+        _, ws1 = K.igemm_query(T, GEMM_S1, B, s.H, s.W, cin, 0, self.n4, [self.n4], ks=1)
+        ws2 = K.igemm_query(T, GEMM_S1, B, s.H, s.W, self.n4, 0, cin, [cin], ks=1)[1] if s.needs_grad else 0
+        ws3 = K.wgrad_workspace_bytes(T, B, s.H, s.W, cin, 0, self.n4, 0, ks=1)
+        ws4 = K.channel_sum_workspace_bytes(B * o.H * o.W, cout) if self.bias4 is not None else 0
+        self._ws = max(ws1, ws2, ws3, ws4)
+
+    def workspace_bytes(self, eng):
+        return self._ws
+
+    def pack(self, eng):
+        master = eng._flat_slice(eng.flat_p, self.convt.weight)                         # [Cin][tap][Cout]
+        K.pack_transpose_taps(master, self.cin, 1, self.n4, self.w_fwd, flip=False)
+        if self.w_dg is not None:
+            K.pack_rows(master, self.cin, 1, self.n4, self.w_dg)
+        if self.bias4 is not None:
+            self.bias4.view(4, self.cout).copy_(eng._flat_slice(eng.flat_p, self.convt.bias).view(1, self.cout).expand(4, -1))
+
+    def fwd(self, eng, training):
+        s = self.src
+        K.igemm(eng.dtype, GEMM_S1, eng.B, s.H, s.W, s.data, None, self.w_fwd, self.n4, EPI_ADD,
+                [K.Seg(self.n4, out0=self.tmp, bias=self.bias4)], eng.workspace, ks=1)
+        K.pixel_shuffle2(self.tmp, self.out.data)
+
+    def bwd(self, eng):
+        T, B, s, o = eng.dtype, eng.B, self.src, self.out
+        fg = lambda p: eng._flat_slice(eng.flat_g, p)
+        if self.bias4 is not None:
+            K.channel_sum(o.grad, B * o.H * o.W, self.cout, self.cout, fg(self.convt.bias), eng.workspace)
+            eng._mark(self.convt.bias)
+        K.pixel_shuffle2(self.tmp, o.grad, inverse=True)                              # tmp = d loss / d (GEMM output)
+        K.wgrad(T, B, s.H, s.W, s.data, None, self.tmp, None, fg(self.convt.weight), eng.workspace, ks=1)
+        eng._ready(self.convt.weight)
+        if self.w_dg is not None:
+            tgt = s.target()
+            K.igemm(T, GEMM_S1, B, s.H, s.W, self.tmp, None, self.w_dg, self.cin, EPI_ADD,
+                    [K.Seg(self.cin, out0=s.grad, accumulate=tgt.written)], eng.workspace, ks=1)
+            tgt.written = True
+
+
 class Head1x1(Op):
     """Conv2d(C, 1, 1) + clamp(0, max_depth) (act 0) or sigmoid * max_depth + clamp (act 1); f32 [B,1,H,W] out."""
 

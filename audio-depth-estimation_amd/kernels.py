@@ -359,6 +359,17 @@ def upsample2x_bwd(gdst, gsrc, accumulate=False):
               int(bool(accumulate)), dtype_code(gsrc.dtype), _stream())
 
 
+def pixel_shuffle2(packed, spatial, inverse=False):
+    """packed [B,H,W,4*C] (tap-major) <-> spatial [B,2H,2W,C]: the scatter of ConvTranspose2d(k 2, s 2) / the gather of
+    its gradient (inverse)."""
+    B, H, W, C4 = packed.shape
+    assert spatial.shape == (B, 2 * H, 2 * W, C4 // 4) and packed.dtype == spatial.dtype
+    _dev(packed, spatial)
+    src, dst = (spatial, packed) if inverse else (packed, spatial)
+    _lib.call('adn_pixel_shuffle2', ptr(src), ptr(dst), B, H, W, C4 // 4, int(bool(inverse)), dtype_code(packed.dtype),
+              _stream())
+
+
 def relu_bwd_stats_num_partials(pixels, Cc):
     return _lib.load().adn_relu_bwd_stats_num_partials(pixels, Cc)
 

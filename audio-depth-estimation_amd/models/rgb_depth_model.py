@@ -10,7 +10,7 @@ import torch.nn as nn
 import torch.nn.functional as F  # noqa: F401  (the reference module exports it)
 from torch.nn import init
 
-from ..dc_engine import Act, ConvBNReLU, DCEngine, Head1x1, MaxPool2, Upsample2x, run_dcnet
+from ..dc_engine import Act, ConvBNReLU, ConvT2x2, DCEngine, Head1x1, MaxPool2, Upsample2x, run_dcnet
 from .unetbaseline_model import default_compute_dtype
 
 
@@ -85,9 +85,10 @@ class Up(nn.Module):
         _inner('Up')
 
     def adn_ops(self, x1, x2, out_name):
-        if not isinstance(self.up, nn.Upsample):
-            raise NotImplementedError('bilinear=False (ConvTranspose2d k2 s2 upsampling) is not implemented on the '
-                                      'libadn path; every reference entry point defaults to bilinear=True')
+        if not isinstance(self.up, nn.Upsample):                         # bilinear=False: ConvTranspose2d(k 2, s 2)
+            up = Act(out_name + '.up', x1.C // 2, x2.H, x2.W)
+            ops, out = self.conv.adn_ops([x2, up], out_name, x2.H, x2.W)
+            return [ConvT2x2(x1, self.up, up)] + ops, out
         if x2.H < 2 * x1.H or x2.W < 2 * x1.W:
             raise NotImplementedError('negative padding (skip smaller than the upsampled tensor) cannot occur with '
                                       'MaxPool2d(2) encoders and is not implemented')

@@ -160,6 +160,12 @@ int adn_upsample2x_fwd(const void* src, void* dst, int32_t B, int32_t Hi, int32_
                        int32_t Wo, int32_t C, int32_t dtype, void* stream);
 int adn_upsample2x_bwd(const void* gdst, void* gsrc, int32_t B, int32_t Hi, int32_t Wi, int32_t Ho,
                        int32_t Wo, int32_t C, int32_t accumulate, int32_t dtype, void* stream);
+/* nn.ConvTranspose2d(C_in, C, kernel_size=2, stride=2) of `Up(bilinear=False)` (binaural_attention_model.py:64-67,
+ * rgb_depth_model.py:63-66) = a 1x1 implicit GEMM (adn_igemm, ADN_GEMM_S1, ks 1) to packed [B][H][W][4][C] (tap
+ * t = 2i + j) + this shuffle: spatial [B][2H][2W][C] with spatial[b][2y+i][2x+j][c] = packed[b][y][x][2i+j][c].
+ * inverse = 0: src packed -> dst spatial; inverse = 1: src spatial -> dst packed (gradient gather). */
+int adn_pixel_shuffle2(const void* src, void* dst, int32_t B, int32_t H, int32_t W, int32_t C,
+                       int32_t inverse, int32_t dtype, void* stream);
 /* ReLU + BatchNorm backward, first pass, for a gradient that did not come through a GEMM epilogue:
  * g <- g * (y > 0) in place and partial sums [P][2][C] of g and g * xhat for adn_bn_bwd_finalize
  * (P = adn_relu_bwd_stats_num_partials). */

@@ -83,8 +83,13 @@ def down(sd, prefix, x, training, new_stats):
 
 
 def up(sd, prefix, x1, x2, training, new_stats):
-    """bilinear x2 (align_corners=True) -> pad to the skip -> cat([skip, up]) -> DoubleConv (:61-77)."""
-    x1 = _q(F.interpolate(x1, scale_factor=2, mode='bilinear', align_corners=True))
+    """bilinear x2 (align_corners=True) -> pad to the skip -> cat([skip, up]) -> DoubleConv (:61-77); with
+    bilinear=False the upsampling is ConvTranspose2d(C, C // 2, kernel_size=2, stride=2) (:64-67), recognised by
+    its parameters in the state dict."""
+    if prefix + '.up.weight' in sd:
+        x1 = _q(F.conv_transpose2d(x1, sd[prefix + '.up.weight'], sd[prefix + '.up.bias'], stride=2))
+    else:
+        x1 = _q(F.interpolate(x1, scale_factor=2, mode='bilinear', align_corners=True))
     dy, dx = x2.shape[2] - x1.shape[2], x2.shape[3] - x1.shape[3]
     x1 = F.pad(x1, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
     return double_conv(sd, prefix + '.conv.double_conv', torch.cat([x2, x1], 1), training, new_stats)

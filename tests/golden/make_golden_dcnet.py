@@ -63,9 +63,9 @@ def perturb_bn(model, seed):
                 m.running_var.copy_(1.0 + 0.5 * torch.rand(m.running_var.shape, generator=g))
 
 
-def rgb_case(name='rgb64_bc8', bc=8, S=64, B=2, lr=1e-4, wd=0.01, max_depth=30.0):
+def rgb_case(name='rgb64_bc8', bc=8, S=64, B=2, lr=1e-4, wd=0.01, max_depth=30.0, bilinear=True):
     torch.manual_seed(0)
-    model = quiet(create_rgb_depth_model, base_channels=bc, bilinear=True, output_size=S, max_depth=max_depth)
+    model = quiet(create_rgb_depth_model, base_channels=bc, bilinear=bilinear, output_size=S, max_depth=max_depth)
     perturb_bn(model, 1)
     with torch.no_grad():
         model.outc.bias.fill_(2.0)          # most pixels inside the clamp range; some still hit clamp(0)
@@ -281,6 +281,8 @@ if __name__ == '__main__':
     which = _sys.argv[1:] or ['rgb', 'binaural', 'adabins', 'baseres']
     if 'rgb' in which:
         rgb_case()
+    if 'rgbconvt' in which:             # Up(bilinear=False): ConvTranspose2d(k 2, s 2) upsampling
+        rgb_case('rgbconvt64_bc8', bilinear=False)
     if 'binaural' in which:
         binaural_case()
     if 'adabins' in which:

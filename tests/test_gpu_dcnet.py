@@ -35,9 +35,11 @@ def max_rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
-def _rgb(bc, S, dtype, sd=None, max_depth=30.0):
+def _rgb(bc, S, dtype, sd=None, max_depth=30.0, bilinear=True):
     from audio_depth_estimation_amd.models.rgb_depth_model import RGBDepthNet
-    model = RGBDepthNet(base_channels=bc, bilinear=True, output_size=S, max_depth=max_depth)
+    if sd is not None:
+        bilinear = 'up1.up.weight' not in sd            # Up(bilinear=False) owns a ConvTranspose2d
+    model = RGBDepthNet(base_channels=bc, bilinear=bilinear, output_size=S, max_depth=max_depth)
     model.compute_dtype = dtype
     if sd is not None:
         model.load_state_dict(sd)
@@ -62,9 +64,10 @@ def _check_sd1(sd_now, z, lr):
             assert float(err.max()) <= 1e-5 * float(ref.abs().max()) + 1e-6, k
 
 
-def test_rgb_golden_reference_parity_f32():
+@pytest.mark.parametrize('fixture', ['rgb64_bc8', 'rgbconvt64_bc8'])      # bilinear=True / ConvTranspose2d upsampling
+def test_rgb_golden_reference_parity_f32(fixture):
     from audio_depth_estimation_amd.engine import FusedTrainer
-    z = np.load(os.path.join(GOLDEN, 'rgb64_bc8.npz'))
+    z = np.load(os.path.join(GOLDEN, fixture + '.npz'))
     bc, S, B = [int(v) for v in z['meta']]
     lr, wd, max_depth, l1w, sw = [float(v) for v in z['hyper']]
     sd0 = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('sd0/')}
@@ -91,7 +94,8 @@ def test_rgb_golden_reference_parity_f32():
     loss.backward()
     for k, prm in model.named_parameters():
         assert prm.grad is not None, k
-        assert max_rel(prm.grad, z['grad/' + k]) <= 2e-3, k
+        # (3e-3 for the ConvTranspose2d variant: one near-zero pre-activation flips a ReLU, as in the binaural case)
+        assert max_rel(prm.grad, z['grad/' + k]) <= (2e-3 if fixture == 'rgb64_bc8' else 3e-3), k
     opt.step()
     _check_sd1(model.state_dict(), z, lr)
 
@@ -119,13 +123,15 @@ def _oracle_step(sd, image, gt, max_depth):
     return pred.detach(), loss.item(), {k: sd[k].grad for k in pkeys}, stats, pred.grad
 
 
+@pytest.mark.parametrize('bilinear', [True, False])
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-def test_rgb_full_width_against_oracle(dtype):
-    """base_channels=64 at 64x64, B=2: every conv runs the MFMA S1 kernels (thin first layer included)."""
+def test_rgb_full_width_against_oracle(dtype, bilinear):
+    """base_channels=64 at 64x64, B=2: every conv runs the MFMA S1 kernels (thin first layer included); with
+    bilinear=False the four ConvTranspose2d(k 2, s 2) upsamplers run as 1x1 MFMA GEMMs + pixel shuffle."""
     from audio_depth_estimation_amd.engine import FusedTrainer
     torch.manual_seed(0)
     S = 64
-    model = _rgb(64, S, dtype)
+    model = _rgb(64, S, dtype, bilinear=bilinear)
     with torch.no_grad():
         model.outc.bias.fill_(2.0)
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
@@ -211,9 +217,9 @@ def test_rgb_error_behaviour():
 
 
 # ---- BinauralAttentionDepthNet --------------------------------------------------------------------------
-def _binaural(bc, S, dtype, sd=None, max_depth=30.0, levels=(2, 3, 4, 5)):
+def _binaural(bc, S, dtype, sd=None, max_depth=30.0, levels=(2, 3, 4, 5), bilinear=True):
     from audio_depth_estimation_amd.models.binaural_attention_model import BinauralAttentionDepthNet
-    model = BinauralAttentionDepthNet(base_channels=bc, bilinear=True, output_size=S, max_depth=max_depth,
+    model = BinauralAttentionDepthNet(base_channels=bc, bilinear=bilinear, output_size=S, max_depth=max_depth,
                                       attention_levels=list(levels))
     model.compute_dtype = dtype
     if sd is not None:
@@ -290,9 +296,10 @@ def test_binaural_golden_reference_parity_f32():
             assert float((sd1[k].cpu() - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-6, k
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-def test_binaural_full_width_against_oracle(dtype):
-    """base_channels=64 at 64x64, B=2 (attention over 1024 / 256 / 64 / 16 tokens): MFMA GEMMs + attention kernels
+@pytest.mark.parametrize('dtype,bilinear', [(torch.float32, True), (torch.bfloat16, True), (torch.float32, False)])
+def test_binaural_full_width_against_oracle(dtype, bilinear):
+    """(bilinear=False: ConvTranspose2d upsampling and a 1024-channel level 5 -- generic attention kernels.)
+    base_channels=64 at 64x64, B=2 (attention over 1024 / 256 / 64 / 16 tokens): MFMA GEMMs + attention kernels
     against the float64 oracle.  f32: as for RGBDepthNet.  bf16: the oracle emulates bf16 storage in the conv
     stacks; this net is ~30 conv/attention stages deep and a freshly initialised BN+ReLU stack amplifies
     perturbations ~1.7x per stage (see the RGB test), so the end-to-end bf16 bounds can only be loose: prediction
@@ -302,7 +309,7 @@ def test_binaural_full_width_against_oracle(dtype):
     from oracle import dcnet_oracle, loss_oracle
     torch.manual_seed(0)
     S = 64
-    model = _binaural(64, S, dtype)
+    model = _binaural(64, S, dtype, bilinear=bilinear)
     g = torch.Generator().manual_seed(7)
     with torch.no_grad():
         for m in model.attention_modules.values():
@@ -343,7 +350,8 @@ def test_binaural_full_width_against_oracle(dtype):
         cos = float(torch.dot(got, ref) / (got.norm() * ref.norm() + 1e-30))
         if f32:
             rl2 = float((got - ref).norm() / (ref.norm() + 1e-30))
-            assert rl2 <= 2e-2 and cos >= 0.9999, (k, rl2, cos)
+            # (gamma is ONE number, a sum over every pixel with heavy cancellation: 5e-2)
+            assert rl2 <= (5e-2 if got.numel() == 1 else 2e-2) and cos >= 0.9999, (k, rl2, cos)
         elif got.numel() == 1:
             # gamma: ONE number that is a sum over every pixel with heavy cancellation -- in bf16 its value (even its
             # sign) is dominated by the amplified rounding noise of this freshly initialised net (generic and MFMA

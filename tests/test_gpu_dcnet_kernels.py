@@ -442,3 +442,19 @@ def test_channel_sum_and_gate_bwd(dtype):
     assert rel_err(dbias, b.grad) <= 1e-5
     assert rel_err(dw, W.grad) <= 1e-5
     assert rel_err(td, att_r.grad) <= TOL_T_OUT[dtype] * 2
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('C', [64, 12, 5])
+def test_pixel_shuffle2_roundtrip(dtype, C):
+    """packed [B,H,W,4,C] <-> spatial [B,2H,2W,C] of ConvTranspose2d(k 2, s 2): exact permutation both ways."""
+    B, H, W = 2, 5, 7
+    g = torch.Generator().manual_seed(3)
+    packed = torch.randn(B, H, W, 4 * C, generator=g).to(dtype).to(DEV)
+    spatial = torch.empty(B, 2 * H, 2 * W, C, dtype=dtype, device=DEV)
+    K().pixel_shuffle2(packed, spatial)
+    want = packed.view(B, H, W, 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * H, 2 * W, C)
+    assert torch.equal(spatial, want)
+    back = torch.empty_like(packed)
+    K().pixel_shuffle2(back, spatial, inverse=True)
+    assert torch.equal(back, packed)

@@ -132,10 +132,11 @@ def _dc_param_keys(z):
     return [k[len('grad/'):] for k in z.files if k.startswith('grad/')]
 
 
-def test_rgbdepthnet_oracle_matches_reference():
+@pytest.mark.parametrize('fixture', ['rgb64_bc8', 'rgbconvt64_bc8'])      # bilinear=True / ConvTranspose2d upsampling
+def test_rgbdepthnet_oracle_matches_reference(fixture):
     """oracle.dcnet_oracle.rgb_forward + depth_loss vs reference RGBDepthNet / DepthLoss / AdamW step."""
     from oracle import dcnet_oracle
-    z = _load('rgb64_bc8')
+    z = _load(fixture)
     lr, wd, max_depth, l1w, sw = [float(v) for v in z['hyper']]
     sd = _sd(z, 'sd0/')
     image, gt = torch.from_numpy(z['image']), torch.from_numpy(z['gt'])
