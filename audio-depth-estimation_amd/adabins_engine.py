@@ -13,7 +13,6 @@ from __future__ import annotations
 
 import torch
 
-from . import _lib
 from . import kernels as K
 from .dc_engine import Act, ConvBNReLU, DCEngine, Head1x1, Op, flag_solo
 from .engine import GraphedStep

@@ -23,7 +23,7 @@ import torch
 
 from . import _lib
 from . import kernels as K
-from .flat import FlatParamEngine, _align
+from .flat import FlatParamEngine
 from ._lib import EPI_ACT, EPI_BWD, EPI_FINAL, EPI_Z_STATS, GEMM_S2, GEMM_T2
 
 BN_EPS = 1e-5

@@ -105,7 +105,6 @@ def main():
     args = ap.parse_args()
 
     from audio_depth_estimation_amd import ddp as addp
-    from audio_depth_estimation_amd import kernels as K
     from audio_depth_estimation_amd.engine import FusedTrainer
     from audio_depth_estimation_amd.models.unetbaseline_model import define_G
 
