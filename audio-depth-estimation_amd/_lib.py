@@ -167,6 +167,8 @@ _PROTOS = {
     'adn_frontend': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int64,
                                c_void_p]),
     'adn_resize_bilinear': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    'adn_resize_bilinear_bwd': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    'adn_clamp_range': (C.c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -332,6 +332,7 @@ __global__ __launch_bounds__(256) void relu_bwd_stats_kernel(T* g, const T* y, c
 // 1x1 conv to ONE channel + output activation (outc + clamp / sigmoid*max_depth:
 // rgb_depth_model.py:195-209, binaural_attention_model.py:330-337).  One pixel per LPP-lane group.
 //   act 0: out = clamp(z, 0, max_depth)      act 1: out = clamp(sigmoid(z) * max_depth, 0, max_depth)
+//   act 2: out = tanh(z) * max_depth         act 3: out = z (the clamp follows the final resize, adn_clamp_range)
 template <typename T, int V>
 __global__ __launch_bounds__(256) void head1x1_fwd_kernel(const T* x, const float* w, const float* bias,
                                                           int64_t pixels, int C, int lpp, int act, float maxd,
@@ -357,11 +358,22 @@ __global__ __launch_bounds__(256) void head1x1_fwd_kernel(const T* x, const floa
       zpre[pix] = zz;
       if (act == 2) {
         out[pix] = tanhf(zz) * maxd;
+      } else if (act == 3) {
+        out[pix] = zz;
       } else {
         float o_ = act == 1 ? maxd / (1.f + __expf(-zz)) : zz;
         out[pix] = fminf(fmaxf(o_, 0.f), maxd);
       }
     }
+  }
+}
+
+// torch.clamp(x, 0, max_depth) after the final resize (rgb_depth_model.py:209) and its backward (the gradient passes
+// on the closed interval, as torch.clamp does)
+__global__ __launch_bounds__(256) void clamp_range_kernel(const float* x, const float* g, int64_t n, float maxd, float* out) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const float v = x[e];
+    out[e] = g ? ((v >= 0.f && v <= maxd) ? g[e] : 0.f) : fminf(fmaxf(v, 0.f), maxd);
   }
 }
 
@@ -393,6 +405,8 @@ __global__ __launch_bounds__(256) void head1x1_bwd_kernel(const float* gout, con
     } else if (act == 2) {
       const float t = tanhf(zz);
       d = maxd * (1.f - t * t);
+    } else if (act == 3) {
+      d = 1.f;
     } else {
       d = (zz >= 0.f && zz <= maxd) ? 1.f : 0.f;
     }
@@ -629,6 +643,14 @@ extern "C" int adn_pixel_shuffle2(const void* src, void* dst, int32_t B, int32_t
   return ADN_OK;
 }
 
+extern "C" int adn_clamp_range(const float* x, const float* g, int64_t n, float max_depth, float* out, void* stream) {
+  ADN_CHECK_ARG(x && out && n > 0, "adn_clamp_range: bad arguments");
+  hipLaunchKernelGGL(clamp_range_kernel, dim3(blocks_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, g, n,
+                     max_depth, out);
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}
+
 extern "C" int64_t adn_relu_bwd_stats_num_partials(int64_t pixels, int32_t C) {
   if (pixels <= 0 || C <= 0) return -1;
   int64_t p = adn_cdiv(pixels, 256);
@@ -664,7 +686,7 @@ extern "C" int adn_head1x1_fwd(const void* x, const float* w, const float* bias,
                                int32_t dtype, int32_t act, float max_depth, float* zpre, float* out, void* stream) {
   ADN_CHECK_ARG(x && w && zpre && out && pixels > 0 && C > 0, "adn_head1x1_fwd: bad arguments");
   ADN_CHECK_ARG(dtype == ADN_F32 || dtype == ADN_BF16, "adn_head1x1_fwd: bad dtype %d", dtype);
-  ADN_CHECK_ARG(act >= 0 && act <= 2, "adn_head1x1_fwd: bad act %d", act);
+  ADN_CHECK_ARG(act >= 0 && act <= 3, "adn_head1x1_fwd: bad act %d", act);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int V = (C & 7) == 0 ? 8 : 1;
   const int lpp = head_lpp(C, V);
@@ -694,7 +716,7 @@ extern "C" int adn_head1x1_bwd(const float* gout, const float* zpre, const void*
                                void* workspace, int64_t workspace_bytes, void* stream) {
   ADN_CHECK_ARG(gout && zpre && x && w && gx && dw && pixels > 0 && C > 0, "adn_head1x1_bwd: bad arguments");
   ADN_CHECK_ARG(dtype == ADN_F32 || dtype == ADN_BF16, "adn_head1x1_bwd: bad dtype %d", dtype);
-  ADN_CHECK_ARG(act >= 0 && act <= 2, "adn_head1x1_bwd: bad act %d", act);
+  ADN_CHECK_ARG(act >= 0 && act <= 3, "adn_head1x1_bwd: bad act %d", act);
   const int V = (C & 7) == 0 ? 8 : 1;
   const int lpp = head_lpp(C, V);
   ADN_CHECK_ARG(C <= lpp * V * kHeadIt, "adn_head1x1_bwd: C = %d too large (max %d)", C, lpp * V * kHeadIt);

@@ -241,6 +241,60 @@ extern "C" int adn_resize_bilinear(const float* src, int32_t planes, int32_t H, 
   return ADN_OK;
 }
 
+// Adjoint of the non-antialiased bilinear resize above ([planes][H][W] -> [planes][S][S], align_corners=False): one thread
+// per SOURCE pixel gathers the output gradients that interpolate from it, with the forward's own index / weight
+// arithmetic (no atomics: the candidate output rows / columns of a source row are a short contiguous range).
+__device__ __forceinline__ void resize_src(int o, float scale, int n, int& i0, int& i1, float& l) {
+  const float s = fmaxf((o + 0.5f) * scale - 0.5f, 0.f);
+  i0 = min((int)s, n - 1);
+  i1 = min(i0 + 1, n - 1);
+  l = s - i0;
+}
+__global__ __launch_bounds__(256) void resize_bilinear_bwd_kernel(const float* gout, int planes, int H, int W, int S,
+                                                                  float* gin) {
+  const float sy = (float)H / S, sx = (float)W / S;
+  const int64_t n = (int64_t)planes * H * W;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const int ix = (int)(e % W), iy = (int)((e / W) % H);
+    const int64_t pl = e / ((int64_t)W * H);
+    // outputs whose i0 is iy - 1 or iy: (o + 0.5) * scale - 0.5 in [iy - 1, iy + 1)
+    const int oy_lo = max((int)floorf(((float)iy - 0.5f) / sy - 0.5f) - 1, 0);
+    const int oy_hi = min((int)ceilf(((float)iy + 1.5f) / sy - 0.5f) + 1, S - 1);
+    const int ox_lo = max((int)floorf(((float)ix - 0.5f) / sx - 0.5f) - 1, 0);
+    const int ox_hi = min((int)ceilf(((float)ix + 1.5f) / sx - 0.5f) + 1, S - 1);
+    const float* g = gout + pl * S * S;
+    float acc = 0.f;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      int y0, y1;
+      float ly;
+      resize_src(oy, sy, H, y0, y1, ly);
+      const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+      if (wy == 0.f) continue;
+      float row = 0.f;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        int x0, x1;
+        float lx;
+        resize_src(ox, sx, W, x0, x1, lx);
+        const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+        if (wx != 0.f) row += wx * g[oy * S + ox];
+      }
+      acc += wy * row;
+    }
+    gin[e] = acc;
+  }
+}
+
+extern "C" int adn_resize_bilinear_bwd(const float* gout, int32_t planes, int32_t H, int32_t W, int32_t S, float* gin,
+                                       void* stream) {
+  ADN_CHECK_ARG(gout && gin && planes > 0 && H > 0 && W > 0 && S > 0, "adn_resize_bilinear_bwd: bad arguments");
+  int64_t blocks = adn_cdiv((int64_t)planes * H * W, 256);
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(resize_bilinear_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), gout, planes, H, W, S, gin);
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}
+
 // ---- depth-target preparation (BatvisionV2_Dataset.py:65-78, BatvisionV1_Dataset.py:45-64) -------------------------
 // raw depth in millimetres (f32 / u16 / i32) -> metres, NaN / +-inf -> 0, clip to max_depth (when > 0), negatives -> 0,
 // cv2.INTER_NEAREST resize (source index = min(floor(dst * in / out), in - 1)), optional / norm.

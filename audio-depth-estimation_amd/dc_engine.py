@@ -358,11 +358,17 @@ class ConvT2x2(Op):
 
 
 class Head1x1(Op):
-    """Conv2d(C, 1, 1) + clamp(0, max_depth) (act 0) or sigmoid * max_depth + clamp (act 1); f32 [B,1,H,W] out."""
+    """Conv2d(C, 1, 1) + clamp(0, max_depth) (act 0) or sigmoid * max_depth + clamp (act 1); f32 [B,1,H,W] out.
+    With ``out_size`` != the source size the reference resizes BEFORE the clamp (F.interpolate(bilinear,
+    align_corners=False), rgb_depth_model.py:200-209, binaural_attention_model.py:326-337): the head then runs
+    unclamped (act 0 -> identity), adn_resize_bilinear and adn_clamp_range follow; backward in reverse."""
 
-    def __init__(self, src, conv, act, max_depth):
+    def __init__(self, src, conv, act, max_depth, out_size=None):
         self.src, self.conv, self.act, self.max_depth = src, conv, act, float(max_depth)
         assert conv.kernel_size == (1, 1) and conv.out_channels == 1
+        self.out_size = out_size                  # the caller applies the reference's rule (width != output_size)
+        if self.out_size is not None:
+            self.act = {0: 3, 1: 1}[act]          # sigmoid * max_depth already lies inside the clamp range
         src.consumers.append(self)
 
     def prepare(self, eng):
@@ -371,6 +377,11 @@ class Head1x1(Op):
         f32 = dict(dtype=torch.float32, device=eng.dev)
         self.zpre = torch.empty(pixels, **f32)
         self.result = torch.empty(eng.B, 1, s.H, s.W, **f32)
+        if self.out_size is not None:
+            S = self.out_size
+            self.pre, self.gpre = self.result, torch.empty(eng.B, 1, s.H, s.W, **f32)
+            self.resized, self.gres = torch.empty(eng.B, S, S, **f32), torch.empty(eng.B, S, S, **f32)
+            self.result = torch.empty(eng.B, 1, S, S, **f32)
         self._ws = K.head1x1_bwd_workspace_bytes(pixels, s.C)
         self.c_real = getattr(s, 'C_real', s.C)
         if self.c_real != s.C:                          # zero-padded source: padded weight copy / gradient temporary
@@ -387,11 +398,22 @@ class Head1x1(Op):
         return w
 
     def fwd(self, eng, training):
-        K.head1x1_fwd(self.src.data, self._weight(eng), self.conv.bias, self.act, self.max_depth, self.zpre, self.result)
+        if self.out_size is None:
+            K.head1x1_fwd(self.src.data, self._weight(eng), self.conv.bias, self.act, self.max_depth, self.zpre,
+                          self.result)
+            return
+        s = self.src
+        K.head1x1_fwd(s.data, self._weight(eng), self.conv.bias, self.act, self.max_depth, self.zpre, self.pre)
+        K.resize_bilinear(self.pre.view(eng.B, s.H, s.W), self.out_size, False, self.resized)
+        K.clamp_range(self.resized, self.max_depth, self.result)
 
     def bwd_head(self, eng, gout):
         s = self.src
         assert not s.written
+        if self.out_size is not None:
+            K.clamp_range(self.resized, self.max_depth, self.gres, g=gout.contiguous())
+            K.resize_bilinear_bwd(self.gres, s.H, s.W, self.gpre.view(eng.B, s.H, s.W))
+            gout = self.gpre
         padded = self.c_real != s.C
         w = self.w_p if padded else eng._flat_slice(eng.flat_p, self.conv.weight)
         db = eng._flat_slice(eng.flat_g, self.conv.bias) if self.conv.bias is not None else None

@@ -318,6 +318,19 @@ def frontend(wave, mode, S, antialias, out, workspace):
               workspace.numel() * workspace.element_size(), _stream())
 
 
+def resize_bilinear_bwd(gout, H, W, gin):
+    """gout f32 [planes, S, S] -> gin f32 [planes, H, W]: adjoint of resize_bilinear(antialias=False)."""
+    _dev(gout, gin)
+    planes, S, _ = gout.shape
+    _lib.call('adn_resize_bilinear_bwd', ptr(gout), planes, H, W, S, ptr(gin), _stream())
+
+
+def clamp_range(x, max_depth, out, g=None):
+    """out = clamp(x, 0, max_depth), or with ``g``: g masked to 0 <= x <= max_depth (the clamp's backward)."""
+    _dev(x, out, g)
+    _lib.call('adn_clamp_range', ptr(x), ptr(g), x.numel(), float(max_depth), ptr(out), _stream())
+
+
 def frontend_workspace_bytes(B, T, mode):
     return _lib.load().adn_frontend_workspace_bytes(B, T, mode)
 

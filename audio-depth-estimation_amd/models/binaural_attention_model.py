@@ -113,10 +113,6 @@ class BinauralAttentionDepthNet(nn.Module):
         if C != 2:
             raise RuntimeError(f'expected input[{B}, {C}, {H}, {W}] to have 2 channels (left, right), but got {C} '
                                'channels instead')
-        if H != self.output_size or W != self.output_size:
-            raise NotImplementedError(f'input {H}x{W} != output_size {self.output_size}: the final bilinear resize '
-                                      '(reference :326-332) is not on the libadn path; construct the model with '
-                                      'output_size equal to the input size as train_binaural_attention.py does')
         left, right = eng.thin_input('left', 1, H, W), eng.thin_input('right', 1, H, W)
         ops_l, fl = self.left_encoder.adn_ops(left, 'L', H, W)
         ops_r, fr = self.right_encoder.adn_ops(right, 'R', H, W)
@@ -140,7 +136,8 @@ class BinauralAttentionDepthNet(nn.Module):
         for i, up in enumerate((self.up1, self.up2, self.up3, self.up4)):
             o, d = up.adn_ops(d, fused[3 - i], f'd{4 - i}')
             ops += o
-        head = Head1x1(d, self.outc[0], 1, self.max_depth)                       # sigmoid * max_depth, clamp
+        head = Head1x1(d, self.outc[0], 1, self.max_depth,                       # sigmoid * max_depth, [resize,] clamp
+                       out_size=self.output_size if W != self.output_size else None)
         return [(left, 0, 1), (right, 1, 1)], ops, head
 
     def engine(self):

@@ -137,10 +137,6 @@ class RGBDepthNet(nn.Module):
         if C != 3:
             raise RuntimeError(f'Given groups=1, weight of size {list(self.inc.double_conv[0].weight.shape)}, '
                                f'expected input[{B}, {C}, {H}, {W}] to have 3 channels, but got {C} channels instead')
-        if H != self.output_size or W != self.output_size:
-            raise NotImplementedError(f'input {H}x{W} != output_size {self.output_size}: the final bilinear resize '
-                                      '(reference :200-206) is not on the libadn path; construct the model with '
-                                      'output_size equal to the input size as train_rgb_depth.py does')
         x = eng.thin_input('x', 3, H, W)
         ops, x1 = self.inc.adn_ops([x], 'x1', H, W)
         feats = [x1]
@@ -152,7 +148,8 @@ class RGBDepthNet(nn.Module):
         for i, up in enumerate((self.up1, self.up2, self.up3, self.up4)):
             o, d = up.adn_ops(d, feats[3 - i], f'd{4 - i}')
             ops += o
-        head = Head1x1(d, self.outc, 0, self.max_depth)
+        # (reference :200-206: the head output is resized when its WIDTH differs from output_size)
+        head = Head1x1(d, self.outc, 0, self.max_depth, out_size=self.output_size if W != self.output_size else None)
         return [(x, 0, 3)], ops, head
 
     def engine(self):

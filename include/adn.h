@@ -174,6 +174,7 @@ int adn_relu_bwd_stats(void* g, const void* y, const void* z, const float* mean,
                        int64_t pixels, int32_t C, int32_t dtype, float* partials, void* stream);
 /* 1x1 conv to one channel + output activation (rgb_depth_model.py:195-209: outc, clamp(0, max_depth);
  * binaural_attention_model.py:330-337: sigmoid(outc) * max_depth, clamp).  act 0 clamp, 1 sigmoid,
+ * 3: identity (the clamp follows the final resize, adn_clamp_range);
  * 2: tanh(z) * max_depth with no clamp (AdaBins residual head, adabins_distillation_model.py:330-335; pass
  * max_depth = 0.05 * cfg max_depth).
  * zpre/out f32 [pixels]; backward writes gx (dtype [pixels][C]), dw [C], db [1]. */
@@ -183,6 +184,9 @@ int64_t adn_head1x1_bwd_workspace_bytes(int64_t pixels, int32_t C);
 int adn_head1x1_bwd(const float* gout, const float* zpre, const void* x, const float* w, int64_t pixels,
                     int32_t C, int32_t dtype, int32_t act, float max_depth, void* gx, float* dw,
                     float* db, void* workspace, int64_t workspace_bytes, void* stream);
+/* torch.clamp(x, 0, max_depth) applied AFTER the final resize (rgb_depth_model.py:209): g == NULL: out = clamp(x);
+ * g != NULL: out = g where 0 <= x <= max_depth else 0 (its backward).  The head then runs with act 3 (identity). */
+int adn_clamp_range(const float* x, const float* g, int64_t n, float max_depth, float* out, void* stream);
 /* DepthLoss (train_rgb_depth.py:43-87): lambda_l1 * mean|p-g| + lambda_smooth * (mean|dx p| + mean|dy p|),
  * unmasked.  stats f64[4] = [sum|p-g|, sum|dx|, sum|dy|, 0]; a data-parallel caller all-reduces stats and
  * passes replicas = world size (the means are over the global batch). */
@@ -421,6 +425,11 @@ int adn_depth_prepare(const void* src, int32_t src_type, int32_t planes, int32_t
 /* transforms.Resize((S,S)) alone (utils_dataset.py:18-20): src f32 [planes][H][W] -> out [planes][S][S]. */
 int adn_resize_bilinear(const float* src, int32_t planes, int32_t H, int32_t W, int32_t S,
                         int32_t antialias, float* out, void* stream);
+/* Gradient of the non-antialiased resize (the models' final F.interpolate(..., mode='bilinear', align_corners=False)
+ * when output_size != input size: rgb_depth_model.py:200-206, binaural_attention_model.py:326-333):
+ * gout [planes][S][S] -> gin [planes][H][W], a gather per source pixel (deterministic, no atomics). */
+int adn_resize_bilinear_bwd(const float* gout, int32_t planes, int32_t H, int32_t W, int32_t S,
+                            float* gin, void* stream);
 
 #ifdef __cplusplus
 }

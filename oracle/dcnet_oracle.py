@@ -112,13 +112,20 @@ def decoder(sd, feats, training, new_stats):
     return outs
 
 
-def rgb_forward(sd, x, max_depth=30.0, training=True, return_features=False):
-    """RGBDepthNet.forward (rgb_depth_model.py:148-218) for output_size == input size.
+def _final_resize(depth, output_size):
+    """F.interpolate(bilinear, align_corners=False) to output_size^2 when the WIDTH differs (rgb_depth_model.py:200-206)."""
+    if output_size is not None and depth.shape[-1] != output_size:
+        depth = F.interpolate(depth, size=(output_size, output_size), mode='bilinear', align_corners=False)
+    return depth
+
+
+def rgb_forward(sd, x, max_depth=30.0, training=True, return_features=False, output_size=None):
+    """RGBDepthNet.forward (rgb_depth_model.py:148-218); output_size=None means output_size == input size.
     Returns (depth, new_running_stats[, features])."""
     new_stats = {}
     feats = encoder(sd, '', _q(x), training, new_stats)
     ds = decoder(sd, feats, training, new_stats)
-    depth = F.conv2d(ds[3], sd['outc.weight'], sd['outc.bias'])
+    depth = _final_resize(F.conv2d(ds[3], sd['outc.weight'], sd['outc.bias']), output_size)
     depth = torch.clamp(depth, 0, max_depth)                                  # :209
     if return_features:
         f = {f'x{i + 1}': feats[i] for i in range(5)}
@@ -146,7 +153,7 @@ def cross_attention(sd, prefix, left, right):
     return attend(left, right), attend(right, left)
 
 
-def binaural_forward(sd, x, max_depth=30.0, attention_levels=(2, 3, 4, 5), training=True):
+def binaural_forward(sd, x, max_depth=30.0, attention_levels=(2, 3, 4, 5), training=True, output_size=None):
     """BinauralAttentionDepthNet.forward (binaural_attention_model.py:280-340), output_size == input size."""
     new_stats = {}
     lf = encoder(sd, 'left_encoder.', x[:, 0:1], training, new_stats)
@@ -161,7 +168,7 @@ def binaural_forward(sd, x, max_depth=30.0, attention_levels=(2, 3, 4, 5), train
         fused.append(F.relu(_bn(h, sd, p + '.1', training, new_stats)))
     ds = decoder(sd, fused, training, new_stats)
     depth = torch.sigmoid(F.conv2d(ds[3], sd['outc.0.weight'], sd['outc.0.bias'])) * max_depth
-    return torch.clamp(depth, 0, max_depth), new_stats
+    return torch.clamp(_final_resize(depth, output_size), 0, max_depth), new_stats       # :326-337
 
 
 def depth_loss(pred, target, lambda_l1=1.0, lambda_smooth=0.1):

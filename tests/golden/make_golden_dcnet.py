@@ -63,7 +63,7 @@ def perturb_bn(model, seed):
                 m.running_var.copy_(1.0 + 0.5 * torch.rand(m.running_var.shape, generator=g))
 
 
-def rgb_case(name='rgb64_bc8', bc=8, S=64, B=2, lr=1e-4, wd=0.01, max_depth=30.0, bilinear=True):
+def rgb_case(name='rgb64_bc8', bc=8, S=64, B=2, lr=1e-4, wd=0.01, max_depth=30.0, bilinear=True, in_size=None):
     torch.manual_seed(0)
     model = quiet(create_rgb_depth_model, base_channels=bc, bilinear=bilinear, output_size=S, max_depth=max_depth)
     perturb_bn(model, 1)
@@ -71,7 +71,8 @@ def rgb_case(name='rgb64_bc8', bc=8, S=64, B=2, lr=1e-4, wd=0.01, max_depth=30.0
         model.outc.bias.fill_(2.0)          # most pixels inside the clamp range; some still hit clamp(0)
     out = {'sd0/' + k: v.detach().clone().numpy() for k, v in model.state_dict().items()}
     g = torch.Generator().manual_seed(1234)
-    image = torch.rand(B, 3, S, S, generator=g)
+    Si = in_size or S                   # in_size != S: the model resizes its head output to S x S (reference :200-206)
+    image = torch.rand(B, 3, Si, Si, generator=g)
     gt = max_depth * torch.rand(B, 1, S, S, generator=g)
     gt[gt < 0.1 * max_depth] = 0.0
     out['image'], out['gt'] = image.numpy(), gt.numpy()
@@ -281,6 +282,8 @@ if __name__ == '__main__':
     which = _sys.argv[1:] or ['rgb', 'binaural', 'adabins', 'baseres']
     if 'rgb' in which:
         rgb_case()
+    if 'rgbresize' in which:            # 32 x 32 input, output_size 64: final F.interpolate before the clamp
+        rgb_case('rgbresize32to64_bc8', in_size=32)
     if 'rgbconvt' in which:             # Up(bilinear=False): ConvTranspose2d(k 2, s 2) upsampling
         rgb_case('rgbconvt64_bc8', bilinear=False)
     if 'binaural' in which:

@@ -458,3 +458,34 @@ def test_pixel_shuffle2_roundtrip(dtype, C):
     back = torch.empty_like(packed)
     K().pixel_shuffle2(back, spatial, inverse=True)
     assert torch.equal(back, packed)
+
+
+@pytest.mark.parametrize('H,W,S', [(32, 32, 64), (16, 24, 40), (64, 64, 32), (7, 5, 33), (48, 48, 48)])
+def test_resize_bilinear_bwd_is_the_adjoint(H, W, S):
+    """adn_resize_bilinear_bwd vs torch autograd of F.interpolate(bilinear, align_corners=False) (up / down / odd)."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, H, W, generator=g)
+    go = torch.randn(3, S, S, generator=g)
+    xr = x.clone().requires_grad_(True)
+    y = F.interpolate(xr[None], size=(S, S), mode='bilinear', align_corners=False)[0]
+    y.backward(go)
+    out = torch.empty(3, S, S, device=DEV)
+    K().resize_bilinear(x.to(DEV), S, False, out)
+    assert rel_err(out, y.detach()) <= 2e-6
+    gin = torch.empty(3, H, W, device=DEV)
+    K().resize_bilinear_bwd(go.to(DEV), H, W, gin)
+    assert rel_err(gin, xr.grad) <= 2e-6
+
+
+def test_clamp_range_forward_backward():
+    g = torch.Generator().manual_seed(6)
+    x = (40 * torch.rand(5000, generator=g) - 5).to(DEV)
+    x[:3] = torch.tensor([0.0, 30.0, 30.000002], device=DEV)
+    go = torch.randn(5000, generator=g).to(DEV)
+    out, gx = torch.empty_like(x), torch.empty_like(x)
+    K().clamp_range(x, 30.0, out)
+    K().clamp_range(x, 30.0, gx, g=go)
+    xr = x.clone().requires_grad_(True)
+    y = torch.clamp(xr, 0, 30.0)
+    y.backward(go)
+    assert torch.equal(out, y.detach()) and torch.equal(gx, xr.grad)

@@ -132,21 +132,24 @@ def _dc_param_keys(z):
     return [k[len('grad/'):] for k in z.files if k.startswith('grad/')]
 
 
-@pytest.mark.parametrize('fixture', ['rgb64_bc8', 'rgbconvt64_bc8'])      # bilinear=True / ConvTranspose2d upsampling
+# bilinear=True / ConvTranspose2d upsampling / 32x32 input resized to output_size 64 before the clamp
+@pytest.mark.parametrize('fixture', ['rgb64_bc8', 'rgbconvt64_bc8', 'rgbresize32to64_bc8'])
 def test_rgbdepthnet_oracle_matches_reference(fixture):
     """oracle.dcnet_oracle.rgb_forward + depth_loss vs reference RGBDepthNet / DepthLoss / AdamW step."""
     from oracle import dcnet_oracle
     z = _load(fixture)
     lr, wd, max_depth, l1w, sw = [float(v) for v in z['hyper']]
+    S = int(z['meta'][1])
     sd = _sd(z, 'sd0/')
     image, gt = torch.from_numpy(z['image']), torch.from_numpy(z['gt'])
     with torch.no_grad():
-        pe, _ = dcnet_oracle.rgb_forward(sd, image, max_depth, training=False)
+        pe, _ = dcnet_oracle.rgb_forward(sd, image, max_depth, training=False, output_size=S)
     np.testing.assert_allclose(pe.numpy(), z['pred_eval'], rtol=1e-5, atol=1e-5)
     pkeys = _dc_param_keys(z)
     for k in pkeys:
         sd[k] = sd[k].clone().requires_grad_(True)
-    pred, new_stats, feats = dcnet_oracle.rgb_forward(sd, image, max_depth, training=True, return_features=True)
+    pred, new_stats, feats = dcnet_oracle.rgb_forward(sd, image, max_depth, training=True, return_features=True,
+                                                      output_size=S)
     np.testing.assert_allclose(pred.detach().numpy(), z['pred_train'], rtol=1e-5, atol=1e-5)
     for k in ('x1', 'x5', 'd4', 'd1'):
         np.testing.assert_allclose(feats[k].detach().numpy(), z['feat/' + k], rtol=1e-5, atol=1e-5)
