@@ -543,7 +543,7 @@ bool make_plan(const AdnIgemmDesc* d, Plan* pl) {
     ns = (int)(512 / tiles);          // stay within one resident wave of workgroups (256 CUs x 2)
     const int max_by_k = pl->ksteps / 2 > 0 ? pl->ksteps / 2 : 1;
     if (ns > max_by_k) ns = max_by_k;
-    if (ns > 16) ns = 16;          // (deep layers: 16 splits measured 2-5 us faster than 32-64, tools/gemm_bench.py --deep)
+    if (ns > 64) ns = 64;
     if (ns < 1) ns = 1;
   }
   if (const char* e = getenv("ADN_IGEMM_NS")) {             // tuning knob: cap on the split count
