@@ -141,7 +141,23 @@ class BaseResidualTrainer(GraphedStep):
         self.set_weights(c.lambda_recon, c.lambda_base)
 
     def load_state_dict(self, sd, device):
-        raise NotImplementedError('resume of the optimizer state: load the model weights and restart the moments')
+        """Restore what state_dict() saved (flat Adam moments + step counter) -- the 'optimizer_state_dict' entry of the
+        checkpoints written by train_dc._run."""
+        if not self.engine._bound():
+            self.engine.bind_parameters()
+        self._setup_optimizer(torch.device(device))
+        if 'exp_avg' in sd:
+            self.exp_avg.copy_(sd['exp_avg'])
+            self.exp_avg_sq.copy_(sd['exp_avg_sq'])
+            self.state[0] = float(sd['step'])
+
+    def _setup_optimizer(self, dev):
+        if getattr(self, '_opt_ready', False):
+            return
+        eng = self.engine
+        self.state = torch.zeros(8, dtype=torch.float64, device=dev)
+        self.exp_avg, self.exp_avg_sq = torch.zeros_like(eng.flat_p), torch.zeros_like(eng.flat_p)
+        self._opt_ready = True
 
     def set_weights(self, lambda_recon, lambda_base):
         """AdaptiveBaseResidualLoss.set_epoch (utils_base_residual_loss.py:210-229) result."""
@@ -150,12 +166,12 @@ class BaseResidualTrainer(GraphedStep):
     def _setup(self, pred):
         eng, dev = self.engine, pred.device
         f64, f32 = dict(dtype=torch.float64, device=dev), dict(dtype=torch.float32, device=dev)
-        self.state, self.lstats, self.bstats = torch.zeros(8, **f64), torch.zeros(4, **f64), torch.zeros(4, **f64)
+        self._setup_optimizer(dev)
+        self.lstats, self.bstats = torch.zeros(4, **f64), torch.zeros(4, **f64)
         self.loss_ws, self.norm_ws = torch.empty(4096 + 8, **f64), torch.empty(1024 + 8, **f64)
         self.recon, self.terms = torch.zeros(1, **f32), torch.zeros(4, **f32)
         self.struct, self.gfinal = torch.empty_like(pred), torch.empty_like(pred)
         self.dbase, self.dres = torch.empty_like(pred), torch.empty_like(pred)
-        self.exp_avg, self.exp_avg_sq = torch.zeros_like(eng.flat_p), torch.zeros_like(eng.flat_p)
         if self.ddp is not None and not self._ready:
             self.ddp.attach(eng)
         self._ready = True

@@ -96,3 +96,37 @@ def test_base_residual_loss_module_and_curriculum():
         ad.set_epoch(epoch)
         w = ad.get_current_weights()
         np.testing.assert_allclose([w['lambda_recon'], w['lambda_base']], want, rtol=1e-6)
+
+
+def test_base_residual_trainer_resume_roundtrip():
+    """state_dict() / load_state_dict() of the fused trainer: a restored trainer + model continues bit-identically."""
+    import copy
+    from audio_depth_estimation_amd.base_residual_engine import BaseResidualTrainer
+    from audio_depth_estimation_amd.models.base_residual_model import BaseResidualDepthNet
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(2, 2, 32, 32, generator=g).to('cuda')
+    gt = (30 * torch.rand(2, 1, 32, 32, generator=g)).to('cuda')
+
+    def make():
+        m = BaseResidualDepthNet(2, 64, True, 32, 30.0)
+        m.compute_dtype = torch.float32
+        return m.to('cuda').train()
+
+    ma = make()
+    ta = BaseResidualTrainer(ma.engine(), use_silog=True, lr=1e-3)
+    for _ in range(2):
+        ta.step(x, gt)
+    sd_model = copy.deepcopy({k: v.detach().clone() for k, v in ma.state_dict().items()})
+    sd_opt = ta.state_dict()
+    assert sd_opt['step'] == 2
+    la, _ = ta.step(x, gt)
+    la = float(la)
+    mb = make()
+    mb.load_state_dict(sd_model)
+    tb = BaseResidualTrainer(mb.engine(), use_silog=True, lr=1e-3)
+    tb.load_state_dict(sd_opt, 'cuda')
+    lb, _ = tb.step(x, gt)
+    assert float(lb) == la
+    for (k, a), (_, b) in zip(ma.state_dict().items(), mb.state_dict().items()):
+        assert torch.equal(a, b), k
