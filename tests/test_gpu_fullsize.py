@@ -1,0 +1,178 @@
+"""Size-independent properties at BASELINE.json's FULL headline configuration (unet_256, ngf 64, batch 32, 256x256) --
+the oracle is too slow there, so the HIP path is checked through what must hold at any size:
+
+  * determinism: two fused train steps from the same state are bit-identical (no float atomics anywhere);
+  * linearity of the backward pass in the upstream gradient (forward fixed): grads(a u + b v) = a grads(u) + b grads(v)
+    -- exercises every dgrad / wgrad / BN-backward kernel at the real tile counts and split-K factors;
+  * eval-mode batch independence: sample i of a batch of 32 equals the same sample run alone (different tilings /
+    split counts of the same layers must agree);
+  * the fused loss + clip + AdamW tail against torch on the very same prediction / gradients.
+f32 compute runs the exact f32 MFMA path (tight bounds); bf16 bounds are the rounding of the stored activations.
+"""
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+B, S = 32, 256
+
+
+def _model(dtype):
+    from audio_depth_estimation_amd.models.unetbaseline_model import define_G
+    torch.manual_seed(0)
+    m = define_G(SimpleNamespace(dataset=SimpleNamespace(depth_norm=False, max_depth=30.0)), 2, 1, 64, 'unet_256')
+    m.compute_dtype = dtype
+    return m.to(DEV)
+
+
+def _batch():
+    g = torch.Generator().manual_seed(1234)
+    audio = torch.rand(B, 2, S, S, generator=g)
+    gt = 30 * torch.rand(B, 1, S, S, generator=g)
+    gt[gt < 3] = 0
+    return audio.to(DEV), gt.to(DEV)
+
+
+def _rel(a, b):
+    return float((a.float() - b.float()).norm() / (b.float().norm() + 1e-30))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_backward_is_linear_in_the_upstream_gradient(dtype):
+    model = _model(dtype).train()
+    eng = model.engine()
+    audio, _ = _batch()
+    pred = eng.forward(audio, True)
+    g = torch.Generator().manual_seed(5)
+    u = torch.randn(pred.shape, generator=g).to(DEV) / pred.numel()
+    v = torch.randn(pred.shape, generator=g).to(DEV) / pred.numel()
+    grads = []
+    for up in (u, v, 0.7 * u - 1.9 * v):
+        eng.backward(up)
+        grads.append(eng.flat_g.clone())
+    want = 0.7 * grads[0] - 1.9 * grads[1]
+    tol = 2e-5 if dtype == torch.float32 else 3e-2          # bf16: every dz tensor is rounded to 8 bits of mantissa
+    assert _rel(grads[2], want) <= tol
+    for p, off, n in eng.param_meta:                         # and per tensor, so a small layer cannot hide
+        a, b = grads[2][off:off + n], want[off:off + n]
+        if float(b.norm()) > 0:
+            assert _rel(a, b) <= 10 * tol, (tuple(p.shape), _rel(a, b))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_eval_batch_independence(dtype):
+    model = _model(dtype).eval()
+    audio, _ = _batch()
+    with torch.no_grad():
+        full = model(audio).clone()
+        for i in (0, 17, 31):
+            one = model(audio[i:i + 1]).clone()
+            err = float((one - full[i:i + 1]).abs().sum() / (full[i:i + 1].abs().sum() + 1e-30))
+            assert err <= (1e-5 if dtype == torch.float32 else 2e-2), (i, err)
+
+
+def test_fused_step_is_deterministic_and_tail_matches_torch():
+    from audio_depth_estimation_amd.engine import FusedTrainer
+    audio, gt = _batch()
+    finals, losses = [], []
+    for _ in range(2):
+        model = _model(torch.bfloat16).train()
+        tr = FusedTrainer(model.engine(), 'Combined', 0.5, 0.5, 0.5, max_depth=30.0, optimizer='AdamW', lr=2e-3, clip_norm=1.0)
+        for _ in range(2):
+            loss, pred = tr.step(audio, gt)
+        losses.append(float(loss))
+        finals.append(model.engine().flat_p.clone())
+    assert losses[0] == losses[1] and torch.equal(finals[0], finals[1])
+    # loss / clip / AdamW tail vs torch on the same prediction and gradients (first step of a fresh model)
+    model = _model(torch.bfloat16).train()
+    eng = model.engine()
+    tr = FusedTrainer(eng, 'Combined', 0.5, 0.5, 0.5, max_depth=30.0, optimizer='AdamW', lr=2e-3, clip_norm=1.0)
+    eng.bind_parameters()
+    p0 = eng.flat_p.clone()
+    loss, pred = tr.step(audio, gt)
+    p = pred.detach().float().clone().requires_grad_(True)
+    mask = gt != 0
+    pp, gg = p[mask], gt[mask]
+    d = torch.log(pp.clamp_min(1e-6)) - torch.log(gg.clamp_min(1e-6))
+    ref = 0.5 * (pp - gg).abs().mean() + 0.5 * torch.sqrt((d ** 2).mean() - 0.5 * d.mean() ** 2)
+    assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref))
+    ref.backward()
+    assert _rel(tr.gout, p.grad) <= 1e-5
+    gflat = eng.flat_g.clone()                                   # gradients of this step (pre-clip values)
+    norm = float(gflat.double().norm())
+    gcl = gflat * min(1.0, 1.0 / (norm + 1e-6))
+    m = 0.1 * gcl
+    vv = 0.001 * gcl * gcl
+    want = p0 * (1 - 2e-3 * 0.01) - 2e-3 * (m / (1 - 0.9)) / ((vv / (1 - 0.999)).sqrt() + 1e-8)
+    err = (eng.flat_p - want).abs()
+    big = gcl.abs() > 1e-7                                       # where Adam's step is well conditioned
+    assert float(err[big].max()) <= 0.02 * 2e-3 and float(err.max()) <= 2.02 * 2e-3
+
+
+def _attn_buffers(B2, N, dqk, dv, seed):
+    T = torch.bfloat16
+    ld = (2 * dqk + dv + 63) // 64 * 64
+    g = torch.Generator().manual_seed(seed)
+    qkv = (0.5 * torch.randn(B2, N, ld, generator=g)).to(T).to(DEV)
+    return qkv, qkv[:, :, :dqk], qkv[:, :, dqk:2 * dqk], qkv[:, :, 2 * dqk:2 * dqk + dv]
+
+
+def test_attention_full_length_properties():
+    """Level-2 cross-attention at its real length (16384 tokens, d_qk 16, d_v 128, MFMA kernels): softmax rows sum to 1
+    (constant V comes back unchanged whatever Q and K are), the key/value batch shift pairs entry b with entry
+    (b + shift) % B2, and the backward is linear in dO with dQ = dK = 0 for a constant V... (dP - delta vanishes)."""
+    from audio_depth_estimation_amd import kernels as K
+    B2, N, dqk, dv = 4, 16384, 16, 128
+    T = torch.bfloat16
+    qkv, q, k, v = _attn_buffers(B2, N, dqk, dv, 21)
+    const = torch.linspace(-2, 2, dv, device=DEV).to(T)
+    vals = torch.stack([const * (b + 1) for b in range(B2)])                 # entry b holds (b+1) * const in every row
+    v.copy_(vals[:, None, :].expand(B2, N, dv))
+    o = torch.empty(B2, N, dv, dtype=T, device=DEV)
+    lse = torch.empty(B2, N, device=DEV)
+    scale = 1.0 / dv ** 0.5
+    K.attn_fwd(q, k, v, o, lse, dqk, dv, B2 // 2, scale)
+    for b in range(B2):
+        want = vals[(b + B2 // 2) % B2].float()
+        assert float((o[b].float() - want).abs().max()) <= 2e-2 * float(want.abs().max()), b
+    assert bool(torch.isfinite(lse).all())
+    # backward with a constant V: dP = dO . V^T is the same for every key, so dS = P (dP - delta) = 0 -> dQ = dK = 0
+    g = torch.Generator().manual_seed(22)
+    do = torch.randn(B2, N, dv, generator=g).to(T).to(DEV)
+    dqkv = torch.zeros_like(qkv)
+    dq, dk, dvg = dqkv[:, :, :dqk], dqkv[:, :, dqk:2 * dqk], dqkv[:, :, 2 * dqk:2 * dqk + dv]
+    ws = torch.empty(B2 * N, device=DEV)
+    K.attn_bwd(q, k, v, o, lse, dqk, dv, B2 // 2, scale, do, dq, dk, dvg, ws)
+    ref_scale = float(do.float().abs().mean())
+    assert float(dq.float().abs().max()) <= 5e-2 * ref_scale and float(dk.float().abs().max()) <= 5e-2 * ref_scale
+    # column sums: sum_k dV[kb][k] = sum_q dO[qb][q] (each softmax row sums to 1), queries of entry b use keys of b + shift
+    for kb in range(B2):
+        qb = (kb - B2 // 2) % B2
+        got, want = dvg[kb].float().sum(0), do[qb].float().sum(0)
+        assert float((got - want).abs().max()) <= 2e-2 * float(want.abs().max()) + 0.5, kb
+
+
+def test_attention_backward_linearity_full_length():
+    from audio_depth_estimation_amd import kernels as K
+    B2, N, dqk, dv = 2, 16384, 16, 128
+    T = torch.bfloat16
+    qkv, q, k, v = _attn_buffers(B2, N, dqk, dv, 31)
+    o = torch.empty(B2, N, dv, dtype=T, device=DEV)
+    lse = torch.empty(B2, N, device=DEV)
+    scale = 1.0 / dv ** 0.5
+    K.attn_fwd(q, k, v, o, lse, dqk, dv, 1, scale)
+    g = torch.Generator().manual_seed(32)
+    u = torch.randn(B2, N, dv, generator=g).to(T).to(DEV)
+    w = torch.randn(B2, N, dv, generator=g).to(T).to(DEV)
+    ws = torch.empty(B2 * N, device=DEV)
+    outs = []
+    for do in (u, w, (u.float() + w.float()).to(T)):
+        d = torch.zeros_like(qkv)
+        K.attn_bwd(q, k, v, o, lse, dqk, dv, 1, scale, do.contiguous(), d[:, :, :dqk], d[:, :, dqk:2 * dqk],
+                   d[:, :, 2 * dqk:2 * dqk + dv], ws)
+        outs.append(d.float())
+    want = outs[0] + outs[1]
+    for lo, hi, name in ((0, dqk, 'dq'), (dqk, 2 * dqk, 'dk'), (2 * dqk, 2 * dqk + dv, 'dv')):
+        assert _rel(outs[2][:, :, lo:hi], want[:, :, lo:hi]) <= 3e-2, name
