@@ -176,3 +176,50 @@ def test_attention_backward_linearity_full_length():
     want = outs[0] + outs[1]
     for lo, hi, name in ((0, dqk, 'dq'), (dqk, 2 * dqk, 'dk'), (2 * dqk, 2 * dqk + dv, 'dv')):
         assert _rel(outs[2][:, :, lo:hi], want[:, :, lo:hi]) <= 3e-2, name
+
+
+@pytest.mark.parametrize('kind', ['rgb', 'binaural'])
+def test_doubleconv_nets_full_size_linearity_and_determinism(kind):
+    """BASELINE configs 3 / 5 shapes at 256^2, batch 32, bf16: RGBDepthNet and BinauralAttentionDepthNet (base 64)."""
+    from audio_depth_estimation_amd.engine import FusedTrainer
+
+    def make():
+        torch.manual_seed(0)
+        if kind == 'rgb':
+            from audio_depth_estimation_amd.models.rgb_depth_model import RGBDepthNet
+            m = RGBDepthNet(64, True, S, 30.0)
+        else:
+            from audio_depth_estimation_amd.models.binaural_attention_model import BinauralAttentionDepthNet
+            m = BinauralAttentionDepthNet(64, True, S, 30.0)
+            with torch.no_grad():
+                for a in m.attention_modules.values():
+                    a.gamma.fill_(0.5)
+        m.compute_dtype = torch.bfloat16
+        return m.to(DEV).train()
+
+    g = torch.Generator().manual_seed(77)
+    x = torch.rand(B, 3 if kind == 'rgb' else 2, S, S, generator=g).to(DEV)
+    gt = (30 * torch.rand(B, 1, S, S, generator=g)).to(DEV)
+    model = make()
+    eng = model.engine()
+    pred = eng.forward(x, True)
+    u = torch.randn(pred.shape, generator=g).to(DEV) / pred.numel()
+    v = torch.randn(pred.shape, generator=g).to(DEV) / pred.numel()
+    grads = []
+    for up in (u, v, 1.3 * u + 0.6 * v):
+        eng.backward(up)
+        grads.append(eng.flat_g.clone())
+    # (bf16 rounding of every stored dz / dS; the binaural net adds four attention stages: measured 3.6e-2)
+    assert _rel(grads[2], 1.3 * grads[0] + 0.6 * grads[1]) <= (3e-2 if kind == 'rgb' else 6e-2)
+    del grads
+    finals = []
+    for _ in range(2):
+        m = make()
+        crit = dict(criterion='DepthLoss', l1_weight=1.0, silog_weight=0.1) if kind == 'rgb' else \
+            dict(criterion='L1', mask_mode='gt0')
+        tr = FusedTrainer(m.engine(), optimizer='AdamW', lr=1e-3, weight_decay=0.01, clip_norm=None, **crit)
+        for _ in range(2):
+            loss, _ = tr.step(x, gt)
+        finals.append((float(loss), m.engine().flat_p.clone()))
+        del m, tr
+    assert finals[0][0] == finals[1][0] and torch.equal(finals[0][1], finals[1][1])
