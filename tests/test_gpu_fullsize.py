@@ -223,3 +223,39 @@ def test_doubleconv_nets_full_size_linearity_and_determinism(kind):
         finals.append((float(loss), m.engine().flat_p.clone()))
         del m, tr
     assert finals[0][0] == finals[1][0] and torch.equal(finals[0][1], finals[1][1])
+
+
+@pytest.mark.parametrize('kind', ['adabins', 'baseres'])
+def test_distillation_trainers_full_size_determinism(kind):
+    """BASELINE config 4 shape (AdaBins distillation, teacher forward + student step) and the Base+Residual sibling at
+    batch 32, 256^2, bf16: two fresh runs of two fused steps are bit-identical and finite."""
+    g = torch.Generator().manual_seed(78)
+    audio, rgb = torch.rand(B, 2, S, S, generator=g).to(DEV), torch.rand(B, 3, S, S, generator=g).to(DEV)
+    gt = 30 * torch.rand(B, 1, S, S, generator=g)
+    gt[gt < 3] = 0
+    gt = gt.to(DEV)
+    finals = []
+    for _ in range(2):
+        torch.manual_seed(0)
+        if kind == 'adabins':
+            from audio_depth_estimation_amd.adabins_engine import AdaBinsTrainer
+            from audio_depth_estimation_amd.models.adabins_distillation_model import AdaBinsDistillationModel
+            m = AdaBinsDistillationModel(128, 64, S, 30.0)
+            m.compute_dtype = torch.bfloat16
+            m = m.to(DEV).train()
+            tr = AdaBinsTrainer(m.engine(), lr=1e-4)
+            step = lambda: tr.step(audio, rgb, gt)
+        else:
+            from audio_depth_estimation_amd.base_residual_engine import BaseResidualTrainer
+            from audio_depth_estimation_amd.models.base_residual_model import BaseResidualDepthNet
+            m = BaseResidualDepthNet(2, 64, True, S, 30.0)
+            m.compute_dtype = torch.bfloat16
+            m = m.to(DEV).train()
+            tr = BaseResidualTrainer(m.engine(), use_silog=True, lr=1e-4)
+            step = lambda: tr.step(audio, gt)
+        for _ in range(2):
+            loss, terms = step()
+        assert bool(torch.isfinite(terms).all())
+        finals.append((float(loss), m.engine().flat_p.clone()))
+        del m, tr
+    assert finals[0][0] == finals[1][0] and torch.equal(finals[0][1], finals[1][1])
