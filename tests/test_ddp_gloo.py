@@ -77,6 +77,28 @@ def _worker(rank, world, port, out):
         red.all_reduce_loss_stats(stats)
         assert torch.equal(stats, torch.tensor([3.0, 6.0, 9.0, 12.0], dtype=torch.float64))
 
+        # ---- 1b. suffix view (AdaBins: the frozen teacher's prefix of the flat buffer is never exchanged): the
+        #          engine reports ABSOLUTE watermarks, the trainer translates them (adabins_engine._GradView)
+        from audio_depth_estimation_amd.adabins_engine import _GradView
+        n, off = 1000, 400
+        full = torch.arange(n, dtype=torch.float32) * (rank + 1)
+        view = _GradView(full[off:])
+        red2 = GradientAllReducer(bucket_bytes=4 * 250)          # 600 trainable elements -> 250 + 250 + 100
+        red2.attach(view)
+        assert red2.buckets == [(350, 600), (100, 350), (0, 100)]
+        hook = lambda lo: view.on_grad_ready(max(0, lo - off))
+        red2.begin_backward()
+        hook(800)
+        assert red2._next == 0
+        hook(740)                                                # absolute 740 = relative 340 <= 350
+        assert red2._next == 1
+        hook(120)                                                # below the prefix boundary: everything trainable is final
+        assert red2._next == 3
+        red2.finish()
+        tot = sum(r + 1 for r in range(world))
+        assert torch.equal(full[off:], torch.arange(off, n, dtype=torch.float32) * tot)
+        assert torch.equal(full[:off], torch.arange(off, dtype=torch.float32) * (rank + 1))      # untouched prefix
+
         # ---- 2. data-parallel step with the oracle
         sd = _model_sd()
         pkeys = unet_oracle.param_keys(7)
