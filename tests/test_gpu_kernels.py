@@ -320,3 +320,33 @@ def test_missing_gpu_tensor_fails_loudly():
     k = K()
     with pytest.raises(RuntimeError):
         k.nchw_to_nhwc(torch.randn(1, 1, 2, 2), torch.empty(1, 2, 2, 1))
+
+
+@pytest.mark.parametrize('P', [7, 256, 257, 3000])
+def test_bn_finalize_many_partial_rows(P):
+    """Both finalize kernels over P partial rows (P > 256 takes the one-workgroup-per-channel variant) vs f64 sums."""
+    k = K()
+    C, cnt = 24, 12345
+    g = torch.Generator().manual_seed(P)
+    part = torch.randn(P, 2, C, generator=g)
+    part[:, 1] = part[:, 1].abs() * 50 + 3          # sum of squares side: positive, variance stays > 0
+    s1, s2 = part[:, 0].double().sum(0), part[:, 1].double().sum(0)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    mu = s1 / cnt
+    var = (s2 / cnt - mu * mu).clamp_min(0)
+    istd_ref = 1.0 / torch.sqrt(var + 1e-5)
+    dev = lambda t: t.float().to(DEV)
+    mean, istd, scale, shift = (torch.empty(C, device=DEV) for _ in range(4))
+    rm_d, rv_d, nbt = dev(rm), dev(rv), torch.zeros(1, dtype=torch.int64, device=DEV)
+    k.bn_fwd_finalize(part.to(DEV).contiguous(), P, C, cnt, dev(gamma), dev(beta), 1e-5, 0.1, rm_d, rv_d, nbt, mean, istd,
+                      scale, shift)
+    assert rel_err(mean, mu) <= 1e-6 and rel_err(istd, istd_ref) <= 1e-6
+    assert rel_err(scale, gamma.double() * istd_ref) <= 1e-6
+    assert rel_err(shift, beta.double() - mu * gamma.double() * istd_ref) <= 1e-5
+    assert rel_err(rm_d, 0.1 * mu) <= 1e-6 and int(nbt) == 1
+    assert rel_err(rv_d, 0.9 + 0.1 * var * cnt / (cnt - 1)) <= 1e-6
+    dgamma, dbeta, coef = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty(2 * C, device=DEV)
+    k.bn_bwd_finalize(part.to(DEV).contiguous(), P, C, cnt, dgamma, dbeta, coef)
+    assert rel_err(dbeta, s1) <= 1e-6 and rel_err(dgamma, s2) <= 1e-6
+    assert rel_err(coef[:C], s1 / cnt) <= 1e-6 and rel_err(coef[C:], s2 / cnt) <= 1e-6
