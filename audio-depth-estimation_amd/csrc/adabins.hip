@@ -274,6 +274,46 @@ __global__ __launch_bounds__(256) void bins_fwd_kernel(const void* logits, const
   }
 }
 
+// bf16, nb % 8 == 0, nb / 8 a power of two <= 64: a pixel's bins are nb / 8 lanes x one 16-byte load each, 64 / (nb / 8)
+// pixels per wave-iteration, reductions across those few lanes only (128 bins: 4 xor steps instead of 6, x4 pixels)
+template <int LPP>
+__global__ __launch_bounds__(256) void bins_fwd_vec_kernel(const uint16_t* logits, const float* centers, int64_t pixels,
+                                                           int HW, float* base) {
+  constexpr int NB = LPP * 8, PPW = 64 / LPP;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int li = lane % LPP, pw = lane / LPP;
+  for (int64_t p0 = ((int64_t)blockIdx.x * 4 + wave) * PPW; p0 < pixels; p0 += (int64_t)gridDim.x * 4 * PPW) {
+    const int64_t pix = p0 + pw;
+    const bool live = pix < pixels;
+    float lv[8];
+    float mx = -INFINITY;
+    if (live) {
+      const u32x4_t c = *reinterpret_cast<const u32x4_t*>(logits + pix * NB + li * 8);
+      Chunk<uint16_t>::unpack(c, lv);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) mx = fmaxf(mx, lv[k]);
+    }
+#pragma unroll
+    for (int o = 1; o < LPP; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float se = 0.f, sc = 0.f;
+    if (live) {
+      const float* cr = centers + (pix / HW) * NB + li * 8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float e = __expf(lv[k] - mx);
+        se += e;
+        sc += e * cr[k];
+      }
+    }
+#pragma unroll
+    for (int o = 1; o < LPP; o <<= 1) {
+      se += __shfl_xor(se, o, 64);
+      sc += __shfl_xor(sc, o, 64);
+    }
+    if (live && li == 0) base[pix] = sc / se;
+  }
+}
+
 // dlogit_k = p_k (c_k - base) dbase + dmean[b][k] / HW;  dcentre partial[b][block][k] = sum_pix p_k dbase
 template <typename T>
 __global__ __launch_bounds__(256) void bins_bwd_kernel(const void* logits, const float* centers, const float* base,
@@ -573,7 +613,12 @@ extern "C" int adn_bins_fwd(const void* logits, const float* centers, int32_t B,
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int64_t pixels = (int64_t)B * HW;
   const dim3 grid(blocks_for(pixels * 64));
-  if (dtype == ADN_BF16) hipLaunchKernelGGL((bins_fwd_kernel<uint16_t>), grid, dim3(256), 0, st, logits, centers, pixels, HW, nb, base);
+  if (dtype == ADN_BF16 && (nb == 128 || nb == 64) && (reinterpret_cast<uintptr_t>(logits) & 15) == 0) {
+    const uint16_t* lg = reinterpret_cast<const uint16_t*>(logits);
+    const dim3 gv(blocks_for(pixels * (nb / 8)));
+    if (nb == 128) hipLaunchKernelGGL((bins_fwd_vec_kernel<16>), gv, dim3(256), 0, st, lg, centers, pixels, HW, base);
+    else hipLaunchKernelGGL((bins_fwd_vec_kernel<8>), gv, dim3(256), 0, st, lg, centers, pixels, HW, base);
+  } else if (dtype == ADN_BF16) hipLaunchKernelGGL((bins_fwd_kernel<uint16_t>), grid, dim3(256), 0, st, logits, centers, pixels, HW, nb, base);
   else hipLaunchKernelGGL((bins_fwd_kernel<float>), grid, dim3(256), 0, st, logits, centers, pixels, HW, nb, base);
   ADN_CHECK_LAUNCH();
   return ADN_OK;
