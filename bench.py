@@ -101,7 +101,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly (default for --gpus > 1)')
     ap.add_argument('--cpu-batch', type=int, default=8)
-    ap.add_argument('--cpu-steps', type=int, default=5)
+    ap.add_argument('--cpu-steps', type=int, default=25)     # B=8: about 12 s of host work (bounded sample)
     args = ap.parse_args()
 
     from audio_depth_estimation_amd import ddp as addp
