@@ -155,12 +155,20 @@ _PROTOS = {
     'adn_convt_n1_workspace_bytes': (c_int64, [c_int32, c_int32, c_int32]),
     'adn_convt_n1_forward': (C.c_int, [c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32,
                                        c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
+    'adn_l0_forward': (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p,
+                                 c_void_p]),
+    'adn_d0_dgrad_num_partials': (c_int64, [c_int32, c_int32, c_int32]),
+    'adn_d0_dgrad': (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, C.POINTER(AdnEpiSeg), C.POINTER(AdnEpiSeg),
+                               c_void_p]),
+    'adn_thin_wgrad_workspace_bytes': (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
+    'adn_thin_wgrad': (C.c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
+                                 c_void_p, c_int64, c_void_p]),
     'adn_sum_to_scalar': (C.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
     'adn_grad_norm': (C.c_int, [c_void_p, c_int64, c_float, c_void_p, c_void_p, c_int64, c_void_p]),
     'adn_grad_norm_workspace_bytes': (c_int64, [c_int64]),
     'adn_optimizer_step': (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_float,
                                      c_float, c_float, c_float, c_int32, c_void_p, c_void_p, c_void_p]),
-    'adn_pack_t2_multi': (C.c_int, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p]),
+    'adn_pack_t2_multi': (C.c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p]),
     'adn_compute_errors': (C.c_int, [c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
     'adn_compute_errors_workspace_bytes': (c_int64, [c_int32, c_int64]),
     'adn_frontend_workspace_bytes': (c_int64, [c_int32, c_int32, c_int32]),

@@ -162,6 +162,12 @@ class AdaBinsEngine(DCEngine):
         self.feat_stats = None
         self.branches = {}
 
+    def bind_parameters(self):
+        super().bind_parameters()
+        # the teacher's parameters are a prefix of parameters(): offset of the first trainable (student) parameter
+        first = next(iter(self.module.audio_encoder.parameters()))
+        self.train_offset = self.offset[id(first)]
+
     # ------------------------------------------------------------------ build
     def _build_branch(self, name, index, Cin, enc, pred, dec, B, H, W, needs_grad):
         m = self.module
@@ -196,7 +202,7 @@ class AdaBinsEngine(DCEngine):
         if not self._bound():
             self.bind_parameters()
         key = (B, H, W, dev)
-        if key == self._shape_key:
+        if self._shape_enter(key):
             return
         m = self.module
         if H != m.output_size or W != m.output_size:
@@ -245,9 +251,6 @@ class AdaBinsEngine(DCEngine):
         self.workspace = torch.empty(ws // 4 + 4, **f32)
         self.weights_dirty = True
         self._shape_key = key
-        # the teacher's parameters are a prefix of parameters(): first trainable offset
-        first = next(iter(m.audio_encoder.parameters()))
-        self.train_offset = self.offset[id(first)]
 
     # ------------------------------------------------------------------ forward of one branch
     def _forward_branch(self, br, x, training):

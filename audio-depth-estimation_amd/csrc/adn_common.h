@@ -132,3 +132,16 @@ __device__ __forceinline__ void mma_tile(const u32x4_t& a, const u32x4_t& b, f32
 }
 
 static inline int64_t adn_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+// Raise a kernel's dynamic-LDS limit exactly once per instantiation.  Launch functions run concurrently on the
+// caller's threads (backward is driven from autograd threads): a plain static flag would be a data race.
+#include <mutex>
+#define ADN_SET_LDS_ONCE(bytes, ...)                                                                       \
+  do {                                                                                                     \
+    static std::once_flag adn_once_;                                                                       \
+    std::call_once(adn_once_, [&] {                                                                        \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(__VA_ARGS__),                                \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (bytes));                      \
+    });                                                                                                    \
+  } while (0)
+
+

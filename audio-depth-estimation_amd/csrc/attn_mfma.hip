@@ -246,12 +246,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_mfma_kernel(FParams p) {
 template <int DQK, int DV, int QT, int NW>
 void launch_fwd(const FParams& p, hipStream_t st) {
   constexpr int lds = 2 * (DV / 128) * 64 * 256;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma_kernel<DQK, DV, QT, NW>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
+  ADN_SET_LDS_ONCE(lds, &attn_fwd_mfma_kernel<DQK, DV, QT, NW>);
   hipLaunchKernelGGL((attn_fwd_mfma_kernel<DQK, DV, QT, NW>), dim3(p.N / (16 * QT * NW), p.B2), dim3(64 * NW), lds, st, p);
 }
 
@@ -582,14 +577,8 @@ __global__ __launch_bounds__(256, DQK == 16 ? 2 : 1) void attn_bwd_dkv_mfma_kern
 template <int DQK, int DV, int QT>
 void launch_bwd(const BParams& p, hipStream_t st) {
   constexpr int lds = 2 * (DV / 128) * 64 * 256 + 2 * 64 * DQK * 2;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_mfma_kernel<DQK, DV, QT>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_mfma_kernel<DQK, DV, QT>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
+  ADN_SET_LDS_ONCE(lds, &attn_bwd_dq_mfma_kernel<DQK, DV, QT>);
+  ADN_SET_LDS_ONCE(lds, &attn_bwd_dkv_mfma_kernel<DQK, DV, QT>);
   const dim3 grid(p.N / (64 * QT), p.B2);
   hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<DQK, DV, QT>), grid, dim3(256), lds, st, p);
   hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<DQK, DV, QT>), grid, dim3(256), lds, st, p);
@@ -597,10 +586,15 @@ void launch_bwd(const BParams& p, hipStream_t st) {
 
 }  // namespace
 
+static bool attn_generic_forced() {   // ADN_ATTN_GENERIC: test knob, read once
+  static const bool forced = getenv("ADN_ATTN_GENERIC") != nullptr;
+  return forced;
+}
+
 // returns 1 when the MFMA kernel took the launch, 0 when the caller must use the generic path
 int adn_attn_mfma_fwd(const AdnAttnDesc* d, hipStream_t st) {
   if (d->dtype != ADN_BF16) return 0;
-  if (getenv("ADN_ATTN_GENERIC")) return 0;
+  if (attn_generic_forced()) return 0;
   int qt;
   if (d->dqk == 16 && d->dv == 128) qt = 2;
   else if (d->dqk == 32 && d->dv == 256) qt = 2;
@@ -629,7 +623,7 @@ int adn_attn_mfma_fwd(const AdnAttnDesc* d, hipStream_t st) {
 // d->workspace already holds D = rowsum(dO * O) (attn.hip computes it before calling)
 int adn_attn_mfma_bwd(const AdnAttnDesc* d, hipStream_t st) {
   if (d->dtype != ADN_BF16) return 0;
-  if (getenv("ADN_ATTN_GENERIC")) return 0;
+  if (attn_generic_forced()) return 0;
   int qt;
   if (d->dqk == 16 && d->dv == 128) qt = 2;
   else if (d->dqk == 32 && d->dv == 256) qt = 2;

@@ -73,13 +73,13 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* src, T* 
 
 // every layer's T2 pack in one launch: blockIdx -> layer by a linear scan of the (tiny) table.  64 x 64 tiles: 256-byte
 // reads of the f32 master rows, 128-byte writes of the bf16 pack rows.
-template <typename T>
-__global__ __launch_bounds__(256) void pack_t2_multi_kernel(const float* flat_master, const int64_t* table, int layers,
+template <typename S, typename T>
+__global__ __launch_bounds__(256) void pack_t2_multi_kernel(const S* flat_master, const int64_t* table, int layers,
                                                             T* t2_base) {
   __shared__ float tile[64][65];
   int l = 0;
   while (l + 1 < layers && (int64_t)blockIdx.x >= table[(l + 1) * 5 + 4]) ++l;
-  const float* master = flat_master + table[l * 5 + 0];
+  const S* master = flat_master + table[l * 5 + 0];
   const int X = (int)table[l * 5 + 1], Y = (int)table[l * 5 + 2];
   T* t2 = t2_base + table[l * 5 + 3];
   const int local = (int)((int64_t)blockIdx.x - table[l * 5 + 4]);
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void pack_t2_multi_kernel(const float* flat_ma
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int x = x0 + ly + 4 * r, y = y0 + lx;
-    tile[ly + 4 * r][lx] = (x < X && y < Y) ? master[((int64_t)x * 16 + tap) * Y + y] : 0.f;
+    tile[ly + 4 * r][lx] = (x < X && y < Y) ? ElemTraits<S>::load(master + ((int64_t)x * 16 + tap) * Y + y) : 0.f;
   }
   __syncthreads();
 #pragma unroll
@@ -458,18 +458,24 @@ extern "C" int adn_bn_bwd_apply(void* g, const void* z, int64_t pixels, int32_t 
   return ADN_OK;
 }
 
-extern "C" int adn_pack_t2_multi(const float* flat_master, const int64_t* table, int32_t layers, int64_t total_blocks,
-                                 int32_t dtype, void* t2_base, void* stream) {
+extern "C" int adn_pack_t2_multi(const void* flat_master, int32_t master_dtype, const int64_t* table, int32_t layers,
+                                 int64_t total_blocks, int32_t dtype, void* t2_base, void* stream) {
   ADN_CHECK_ARG(flat_master && table && layers > 0 && total_blocks > 0 && t2_base, "adn_pack_t2_multi: bad arguments");
   ADN_CHECK_ARG(dtype == ADN_F32 || dtype == ADN_BF16, "adn_pack_t2_multi: bad dtype %d", dtype);
+  ADN_CHECK_ARG(master_dtype == ADN_F32 || (master_dtype == ADN_BF16 && dtype == ADN_BF16),
+                "adn_pack_t2_multi: master dtype %d cannot feed a dtype-%d pack", master_dtype, dtype);
   ADN_CHECK_ARG(total_blocks < (1ll << 31), "adn_pack_t2_multi: too many blocks");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == ADN_BF16)
-    hipLaunchKernelGGL((pack_t2_multi_kernel<uint16_t>), dim3((unsigned)total_blocks), dim3(256), 0, st, flat_master,
-                       table, layers, reinterpret_cast<uint16_t*>(t2_base));
+  if (master_dtype == ADN_BF16)
+    hipLaunchKernelGGL((pack_t2_multi_kernel<uint16_t, uint16_t>), dim3((unsigned)total_blocks), dim3(256), 0, st,
+                       reinterpret_cast<const uint16_t*>(flat_master), table, layers,
+                       reinterpret_cast<uint16_t*>(t2_base));
+  else if (dtype == ADN_BF16)
+    hipLaunchKernelGGL((pack_t2_multi_kernel<float, uint16_t>), dim3((unsigned)total_blocks), dim3(256), 0, st,
+                       reinterpret_cast<const float*>(flat_master), table, layers, reinterpret_cast<uint16_t*>(t2_base));
   else
-    hipLaunchKernelGGL((pack_t2_multi_kernel<float>), dim3((unsigned)total_blocks), dim3(256), 0, st, flat_master, table,
-                       layers, reinterpret_cast<float*>(t2_base));
+    hipLaunchKernelGGL((pack_t2_multi_kernel<float, float>), dim3((unsigned)total_blocks), dim3(256), 0, st,
+                       reinterpret_cast<const float*>(flat_master), table, layers, reinterpret_cast<float*>(t2_base));
   ADN_CHECK_LAUNCH();
   return ADN_OK;
 }

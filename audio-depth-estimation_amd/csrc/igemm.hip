@@ -15,9 +15,31 @@
 #include <stdarg.h>
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "epilogue.h"
 
 namespace {
+
+// Tuning / diagnosis knobs, read from the environment ONCE (not per launch):
+//   ADN_IGEMM_BM / ADN_IGEMM_BN / ADN_IGEMM_NS  force the tile rows / columns, cap the split-K count
+//   ADN_IGEMM_NOA / ADN_IGEMM_NOB               timing-only builds: the gathered / weight operand is read through a
+//                                               zero-record descriptor (every load dropped, zeros in LDS; wrong results)
+struct Tune {
+  int bm = 0, bn = 0, ns = 0, noa = 0, nob = 0;
+};
+const Tune& tune() {
+  static Tune t;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    if (const char* e = getenv("ADN_IGEMM_BM")) t.bm = atoi(e);
+    if (const char* e = getenv("ADN_IGEMM_BN")) t.bn = atoi(e);
+    if (const char* e = getenv("ADN_IGEMM_NS")) t.ns = atoi(e);
+    if (const char* e = getenv("ADN_IGEMM_NOA")) t.noa = atoi(e);
+    if (const char* e = getenv("ADN_IGEMM_NOB")) t.nob = atoi(e);
+  });
+  return t;
+}
 
 struct KParams {
   const void* in0;
@@ -34,6 +56,7 @@ struct KParams {
   int epi;
   AdnEpiSeg seg[2];
   float* slab;    // split-K / generic scratch
+  unsigned rec_a, rec_b;   // buffer-descriptor record bytes of the gathered / weight operands (0 = timing-only build)
 };
 
 
@@ -162,13 +185,13 @@ __global__ __launch_bounds__(BM * NWN, 2) void igemm_mfma_kernel(KParams p) {
 
   typedef __attribute__((address_space(3))) void* lptr_t;
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(reinterpret_cast<const char*>(p.in0) - (int64_t)bshift * p.C0 * ESZ), 0, 0x7ffffff0, 0x00020000);
+      (void*)(reinterpret_cast<const char*>(p.in0) - (int64_t)bshift * p.C0 * ESZ), 0, p.rec_a, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(reinterpret_cast<const char*>(p.C1 ? p.in1 : p.in0) - (int64_t)bshift * p.C1 * ESZ), 0, 0x7ffffff0,
+      (void*)(reinterpret_cast<const char*>(p.C1 ? p.in1 : p.in0) - (int64_t)bshift * p.C1 * ESZ), 0, p.rec_a,
       0x00020000);
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(reinterpret_cast<const char*>(p.w) + (GEOM == ADN_GEMM_T2 ? (int64_t)phase * p.N * ktot * ESZ : 0)), 0,
-      0x7ffffff0, 0x00020000);
+      p.rec_b, 0x00020000);
 
   // scalar K-loop state of the NEXT step to issue: tap index and channel offset inside the tap
   const int kpt = WIDE ? Cin / BK : 1;
@@ -531,8 +554,9 @@ bool make_plan(const AdnIgemmDesc* d, Plan* pl) {
   //  prologue/epilogue better: measured 685 vs 621 TFLOP/s on L1 forward)
   const bool fills256 = adn_cdiv(msmall, 256) * (d->N / pl->bn) * pl->phases >= 256;
   pl->bm = (fills256 && (pl->bn == 64 || taps * Cin / bk >= 32)) ? 256 : 128;
-  if (const char* e = getenv("ADN_IGEMM_BM")) pl->bm = atoi(e) == 256 ? 256 : 128;   // tuning knobs
-  if (const char* e = getenv("ADN_IGEMM_BN")) pl->bn = (atoi(e) == 128 && d->N % 128 == 0) ? 128 : 64;
+  const Tune& tn = tune();
+  if (tn.bm) pl->bm = tn.bm == 256 ? 256 : 128;
+  if (tn.bn) pl->bn = (tn.bn == 128 && d->N % 128 == 0) ? 128 : 64;
   pl->tiles_m = (int)adn_cdiv(msmall, pl->bm);
   pl->tiles_n = d->N / pl->bn;
   pl->kpt = 0;
@@ -546,10 +570,7 @@ bool make_plan(const AdnIgemmDesc* d, Plan* pl) {
     if (ns > 64) ns = 64;
     if (ns < 1) ns = 1;
   }
-  if (const char* e = getenv("ADN_IGEMM_NS")) {             // tuning knob: cap on the split count
-    const int cap = atoi(e);
-    if (cap >= 1 && ns > cap) ns = cap;
-  }
+  if (tn.ns >= 1 && ns > tn.ns) ns = tn.ns;                  // tuning knob: cap on the split count
   pl->nsplit = ns;
   pl->rb = reduce_rows(pl->mout, d->N);
   if (ns > 1) {
@@ -567,12 +588,7 @@ int launch_mfma(const KParams& kp, const Plan& pl, hipStream_t st) {
   const int stage = ((BM_ == 256 && NWN == 2) ? 3 : 2) * (BM_ + BN) * 128;
   const int epil = BM_ * (BN + 4) * 4;
   const int lds = stage > epil ? stage : epil;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_mfma_kernel<T, BM_, BN, NWN, GEOM, WIDE>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
+  ADN_SET_LDS_ONCE(lds, &igemm_mfma_kernel<T, BM_, BN, NWN, GEOM, WIDE>);
   dim3 grid(pl.tiles_m * pl.tiles_n * pl.phases, 1, pl.nsplit);
   hipLaunchKernelGGL((igemm_mfma_kernel<T, BM_, BN, NWN, GEOM, WIDE>), grid, dim3(BM_ * NWN), lds, st, kp);
   return 0;
@@ -618,6 +634,8 @@ int run(const AdnIgemmDesc* d, const Plan& pl, hipStream_t st) {
   kp.seg[0] = d->seg[0];
   kp.seg[1] = d->seg[1];
   kp.slab = reinterpret_cast<float*>(d->workspace);
+  kp.rec_a = tune().noa ? 0u : 0x7ffffff0u;
+  kp.rec_b = tune().nob ? 0u : 0x7ffffff0u;
   if (pl.mfma) {
     if (d->geom == ADN_GEMM_S2) dispatch_mfma<T, ADN_GEMM_S2>(kp, pl, st);
     else if (d->geom == ADN_GEMM_T2) dispatch_mfma<T, ADN_GEMM_T2>(kp, pl, st);

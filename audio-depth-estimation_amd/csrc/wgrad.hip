@@ -505,12 +505,7 @@ int wrun(const AdnWgradDesc* d, const WPlan& pl, hipStream_t st) {
     const bool half = (d->R0 + d->R1) == 64;
 #define ADN_WG_LAUNCH1(FAST_, MIXED_, S1_, HALF_)                                                                      \
   do {                                                                                                         \
-    static bool attr_set = false;                                                                              \
-    if (!attr_set) {                                                                                           \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_kernel<T, FAST_, MIXED_, S1_, HALF_>),      \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);                              \
-      attr_set = true;                                                                                         \
-    }                                                                                                          \
+    ADN_SET_LDS_ONCE(lds, &wgrad_mfma_kernel<T, FAST_, MIXED_, S1_, HALF_>);                                   \
     hipLaunchKernelGGL((wgrad_mfma_kernel<T, FAST_, MIXED_, S1_, HALF_>), grid, dim3(256), lds, st, p);        \
   } while (0)
 #define ADN_WG_LAUNCH(FAST_, MIXED_, S1_)                  \

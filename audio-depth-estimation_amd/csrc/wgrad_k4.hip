@@ -447,14 +447,8 @@ int wrun(const AdnWgradDesc* d, const WPlan& pl, hipStream_t st) {
     constexpr int stage = 4 * BKP * 128 * (int)sizeof(T);
     constexpr int epil = 128 * 132 * 4;
     constexpr int lds = stage > epil ? stage : epil;
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_kernel<T, true>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_kernel<T, false>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      attr_set = true;
-    }
+    ADN_SET_LDS_ONCE(lds, &wgrad_mfma_kernel<T, true>);
+    ADN_SET_LDS_ONCE(lds, &wgrad_mfma_kernel<T, false>);
     if (pl.fast)
       hipLaunchKernelGGL((wgrad_mfma_kernel<T, true>), dim3(pl.tiles_r * pl.tiles_c * pl.nsplit), dim3(256), lds, st, p);
     else

@@ -87,6 +87,10 @@ class BatvisionV2Dataset(Dataset):
         if self._fe is None:
             mode = 'mel_spectrogram' if 'mel' in self.audio_format else 'spectrogram'
             self._fe = GpuAudioFrontend(mode, self.cfg.dataset.images_size, self.antialias)
+        if torch.utils.data.get_worker_info() is not None:
+            raise RuntimeError("frontend='device' transforms on the HIP device and cannot run inside a DataLoader worker "
+                               "process (a forked worker must not touch the device): use num_workers=0, or build the "
+                               "dataset with frontend='raw' and apply GpuAudioFrontend to the batch in the parent")
         dev = torch.device('cuda', torch.cuda.current_device())
         return self._fe(waveform.unsqueeze(0).to(dev))[0].cpu(), gt_depth
 

@@ -597,7 +597,7 @@ class DCEngine(FlatParamEngine):
             self.bind_parameters()
         B, Cin, H, W = x.shape
         key = (B, Cin, H, W, x.device)
-        if key == self._shape_key:
+        if self._shape_enter(key):
             return
         self.B, self.dev = B, x.device
         self._scratch = {}
@@ -633,7 +633,7 @@ class DCEngine(FlatParamEngine):
         return a
 
     def _pack_weights(self):
-        if self.flat_w16 is not None and not self.s2_fresh:
+        if self.flat_w16 is not None and not self._mirror_fresh():
             _lib.record_py(lambda: self.flat_w16.copy_(self.flat_p))
         for op in self.ops:
             if hasattr(op, 'pack'):

@@ -19,6 +19,8 @@ outermost down layer last), which is the bucket order of the data-parallel all-r
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
@@ -29,11 +31,6 @@ from ._lib import EPI_ACT, EPI_BWD, EPI_FINAL, EPI_Z_STATS, GEMM_S2, GEMM_T2
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 LEAKY = 0.2
-
-
-class _Level:
-    """Static + per-shape state of one U-Net level (down conv Li / up convT Di)."""
-    pass
 
 
 class UNetEngine(FlatParamEngine):
@@ -58,6 +55,7 @@ class UNetEngine(FlatParamEngine):
         small pack.  T2 operands: every layer in ONE launch (adn_pack_t2_multi).
         """
         T = self.dtype
+        fresh = self._mirror_fresh()
         for lv in self.levels:
             for key in ('down', 'up'):
                 w = lv[key].weight
@@ -68,9 +66,12 @@ class UNetEngine(FlatParamEngine):
                     K.pack_weights(master, X, Y, T, lv[key + '_s2'], None, y_pad=ypad)
                 elif T == torch.float32:
                     lv[key + '_s2'] = master                       # channels_last memory == S2 operand
-                elif not self.s2_fresh:
+                elif not fresh:
                     K.pack_weights(master, X, Y, T, lv[key + '_s2'], None)
-        K.pack_t2_multi(self.flat_p, self.t2_table, self.t2_layers, self.t2_blocks, T, self.t2_all)
+        # source of the T2 pack: the bf16 mirror when the fused optimizer has just written ALL of it (half the read
+        # traffic, identical values); the f32 masters otherwise (the re-cast above skips the padded edge layers)
+        src = self.flat_w16 if (T == torch.bfloat16 and fresh) else self.flat_p
+        K.pack_t2_multi(src, self.t2_table, self.t2_layers, self.t2_blocks, T, self.t2_all)
         self.weights_dirty = False
         self.s2_fresh = False
         self._packed_version = self._version_sum()
@@ -85,7 +86,7 @@ class UNetEngine(FlatParamEngine):
             raise RuntimeError(f'input {H}x{W} is not divisible by 2^{n}: Kernel size can\'t be greater than '
                                f'actual input size')
         key = (B, Cin, H, W, x.device)
-        if key == self._shape_key:
+        if self._shape_enter(key):
             return
         dev, T = x.device, self.dtype
         f32 = dict(dtype=torch.float32, device=dev)
@@ -101,7 +102,15 @@ class UNetEngine(FlatParamEngine):
         ks = 4 * epc
         self.n1_path = (cout0 == 1 and cu_in0 % 64 == 0 and (cu_in0 // 2) % ks == 0)
         self.cout_pad = epc if self.n1_path else cout0
-        self.x_nhwc = torch.empty(B, H, W, self.cin_pad, dtype=T, device=dev)
+        # Dedicated HBM-bound kernels for the thin outermost layers (csrc/edge.hip; bf16 path, the unet_256 / ngf 64
+        # geometry): first conv 2 -> 64 forward + weight gradient, last transposed conv 128 -> 1 input / weight gradient.
+        # They read the thin operand (network input, output gradient) as planar f32: no channel padding at all.
+        self.edge_path = (T == torch.bfloat16 and self.n1_path and n >= 2 and Cin == 2
+                          and l0['down'].weight.shape[0] == 64 and cu_in0 == 128 and l0['bn_d'] is None
+                          and (W // 2) % 32 == 0 and not os.environ.get('ADN_NO_EDGE'))
+        if self.edge_path:
+            self.cin_pad, self.cout_pad = Cin, cout0
+        self.x_nhwc = None if self.edge_path else torch.empty(B, H, W, self.cin_pad, dtype=T, device=dev)
         for i, lv in enumerate(self.levels):
             dw, uw = lv['down'].weight, lv['up'].weight
             cd_in, cd_out = dw.shape[1], dw.shape[0]
@@ -123,7 +132,7 @@ class UNetEngine(FlatParamEngine):
                 lv['Gu'] = big(cu_out)
             else:
                 lv['out'] = torch.empty(B, 2 * hs, 2 * wsz, cu_out, **f32)
-                lv['dz0'] = big(cu_out_p)
+                lv['dz0'] = torch.empty(B, 1, 2 * hs, 2 * wsz, **f32) if self.edge_path else big(cu_out_p)
             # packed weights: S2 = view of the bf16 parameter mirror (unpadded bf16 layers), own buffer when
             # padded, the f32 master itself on the exact path; T2 = slices of one flat buffer (below)
             for wk, X, Y, Yp in (('down', cd_out, cd_in, cd_in_p), ('up', cu_in, cu_out, cu_out_p)):
@@ -134,17 +143,24 @@ class UNetEngine(FlatParamEngine):
             # GEMM plans: partial rows + workspace
             c_up0 = cd_out
             c_up1 = cu_in - cd_out
-            pd, w1 = K.igemm_query(T, GEMM_S2, B, hs, wsz, cd_in_p, 0, cd_out, [cd_out])          # Li fwd
+            edge0 = i == 0 and self.edge_path
+            pd, w1 = (0, 0) if edge0 else K.igemm_query(T, GEMM_S2, B, hs, wsz, cd_in_p, 0, cd_out, [cd_out])   # Li fwd
             if i == 0 and self.n1_path:
                 pu, w2 = 0, K.convt_n1_workspace_bytes(B, hs, wsz)                                  # D0 fwd
             else:
                 pu, w2 = K.igemm_query(T, GEMM_T2, B, hs, wsz, c_up0, c_up1, cu_out, [cu_out])     # Di fwd
-            pgu, w3 = K.igemm_query(T, GEMM_S2, B, hs, wsz, cu_out_p, 0, cu_in,                     # Di dgrad
-                                    [c_up0, c_up1] if c_up1 else [c_up0])
+            pgu, w3 = (0, 0) if edge0 else K.igemm_query(T, GEMM_S2, B, hs, wsz, cu_out_p, 0, cu_in,   # Di dgrad
+                                                         [c_up0, c_up1] if c_up1 else [c_up0])
             pgd, w4 = (0, 0) if i == 0 else K.igemm_query(T, GEMM_T2, B, hs, wsz, cd_out, 0, cd_in, [cd_in])  # Li dgrad
-            w5 = K.wgrad_workspace_bytes(T, B, hs, wsz, cd_out, 0, cd_in_p, 0, cd_in if cd_in_p != cd_in else 0)
-            w6 = K.wgrad_workspace_bytes(T, B, hs, wsz, c_up0, c_up1, cu_out_p, 0,
-                                         cu_out if cu_out_p != cu_out else 0)
+            w5 = 0 if edge0 else K.wgrad_workspace_bytes(T, B, hs, wsz, cd_out, 0, cd_in_p, 0,
+                                                         cd_in if cd_in_p != cd_in else 0)
+            w6 = 0 if edge0 else K.wgrad_workspace_bytes(T, B, hs, wsz, c_up0, c_up1, cu_out_p, 0,
+                                                         cu_out if cu_out_p != cu_out else 0)
+            if i == 0 and self.edge_path:
+                pgu = K.d0_dgrad_num_partials(B, hs, wsz)
+                w3 = 0
+                w5 = K.thin_wgrad_workspace_bytes(B, hs, wsz, 2, 64, 0)
+                w6 = K.thin_wgrad_workspace_bytes(B, hs, wsz, 1, 64, 64)
             ws_bytes = max(ws_bytes, w1, w2, w3, w4, w5, w6)
             lv.update(P_d=pd, P_u=pu, P_gu=pgu, P_gd=pgd)
             for tag, bn, C in (('d', lv['bn_d'], cd_out), ('u', lv['bn_u'], cu_out)):
@@ -195,13 +211,18 @@ class UNetEngine(FlatParamEngine):
         if self.weights_dirty or self._packed_version != self._version_sum():
             self._pack_weights()
         T, B, n, L, ws = self.dtype, self.B, self.n, self.levels, self.workspace
-        K.nchw_to_nhwc(x, self.x_nhwc)
+        if self.edge_path:
+            self._x_in, self._x_ver = x, x._version          # the first conv and its weight gradient read x itself
+        else:
+            K.nchw_to_nhwc(x, self.x_nhwc)
         # ---- down path
         for i, lv in enumerate(L):
             src = self.x_nhwc if i == 0 else L[i - 1]['ad']
             C, hs, wsz = lv['cd_out'], lv['hs'], lv['ws']
             bn = lv['bn_d']
-            if bn is None:
+            if i == 0 and self.edge_path:
+                K.l0_forward(x, self._flat_slice(self.flat_p, lv['down'].weight), B, hs, wsz, LEAKY, lv['ad'], lv['rd'])
+            elif bn is None:
                 K.igemm(T, GEMM_S2, B, hs, wsz, src, None, lv['down_s2'], C, EPI_ACT,
                         [K.Seg(C, out0=lv['ad'], out1=lv['rd'], slope=LEAKY)], ws, algo_c=lv['cd_in'])
             elif training:
@@ -291,14 +312,19 @@ class UNetEngine(FlatParamEngine):
                 dz = lv['Gu']
             in0 = lv['rd']
             in1 = L[i + 1]['ru'] if i < n - 1 else None
-            K.wgrad(T, B, hs, wsz, in0, in1, dz, None, self._flat_slice(self.flat_g, lv['up'].weight), ws,
-                    c_valid=lv['cu_out'] if (i == 0 and self.cout_pad != lv['cu_out']) else 0)
-            self._ready(lv['up'].weight)
             segs = [K.Seg(lv['cd_out'], out0=lv['Gd'], ref=lv['rd'], slope=0.0)]
             if i < n - 1:
                 nx = L[i + 1]
                 segs.append(K.Seg(nx['cu_out'], out0=nx['Gu'], ref=nx['ru'], slope=0.0, z=nx['zu'],
                                   mean=nx['mean_u'], istd=nx['istd_u'], partials=nx['bpart_u']))
+            if i == 0 and self.edge_path:
+                K.thin_wgrad(dz, in0, in1, B, hs, wsz, self._flat_slice(self.flat_g, lv['up'].weight), ws)
+                self._ready(lv['up'].weight)
+                K.d0_dgrad(dz, self._flat_slice(self.flat_p, lv['up'].weight), B, hs, wsz, segs[0], segs[1])
+                continue
+            K.wgrad(T, B, hs, wsz, in0, in1, dz, None, self._flat_slice(self.flat_g, lv['up'].weight), ws,
+                    c_valid=lv['cu_out'] if (i == 0 and self.cout_pad != lv['cu_out']) else 0)
+            self._ready(lv['up'].weight)
             K.igemm(T, GEMM_S2, B, hs, wsz, dz, None, lv['up_s2'], lv['cu_in'], EPI_BWD, segs, ws,
                     algo_c=lv['cu_out'])
         # ---- down layers, innermost first
@@ -313,8 +339,13 @@ class UNetEngine(FlatParamEngine):
                 K.bn_bwd_apply(lv['Gd'], lv['zd'], B * hs * wsz, C, lv['scale_d'], lv['mean_d'], lv['istd_d'],
                                lv['coef_d'])
             src = self.x_nhwc if i == 0 else L[i - 1]['ad']
-            K.wgrad(T, B, hs, wsz, lv['Gd'], None, src, None, self._flat_slice(self.flat_g, lv['down'].weight), ws,
-                    c_valid=lv['cd_in'] if (i == 0 and self.cin_pad != lv['cd_in']) else 0)
+            if i == 0 and self.edge_path:
+                if self._x_in._version != self._x_ver:
+                    raise RuntimeError('the network input was modified in place between forward and backward')
+                K.thin_wgrad(self._x_in, lv['Gd'], None, B, hs, wsz, self._flat_slice(self.flat_g, lv['down'].weight), ws)
+            else:
+                K.wgrad(T, B, hs, wsz, lv['Gd'], None, src, None, self._flat_slice(self.flat_g, lv['down'].weight), ws,
+                        c_valid=lv['cd_in'] if (i == 0 and self.cin_pad != lv['cd_in']) else 0)
             self._ready(lv['down'].weight)
             if i > 0:
                 pv = L[i - 1]
@@ -369,10 +400,13 @@ class GraphedStep:
     def _graphed(self, *inputs):
         self._calls += 1
         if self._graph is not None:
+            if any((b is None) != (t is None) or (b is not None and b.shape != t.shape) for b, t in zip(self._g_in, inputs)):
+                return self._step_impl(*inputs)          # another batch shape: eager, on that shape's own buffer set
             for buf, t in zip(self._g_in, inputs):
                 if buf is not None:
                     buf.copy_(t)
             self._graph.replay()
+            self.engine.weights_dirty, self.engine.s2_fresh = self._post_flags
             return self._g_out
         if self._graph_after is not None and self._calls > self._graph_after:
             self._g_in = [None if t is None else t.contiguous().float().clone() for t in inputs]
@@ -380,6 +414,10 @@ class GraphedStep:
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
                 self._g_out = self._step_impl(*self._g_in)
+            self.engine.pin_buffers()                    # the graph holds raw pointers into this shape's buffer set
+            # the replayed optimizer step changes the weights behind Python's back: restore the engine's
+            # "operands are stale" flags after every replay (an eval forward in between clears them)
+            self._post_flags = (self.engine.weights_dirty, self.engine.s2_fresh)
             self._graph.replay()            # capture only records: run the step once for real
             return self._g_out
         return self._step_impl(*inputs)
@@ -470,10 +508,14 @@ class FusedTrainer:
 
     def step(self, audio, gt):
         self._calls += 1
+        captured = self._plan is not None or self._graph is not None
+        if captured and (audio.shape != self._g_audio.shape or gt.shape != self._g_gt.shape):
+            return self._step_impl(audio, gt)            # another batch shape: eager, on that shape's own buffer set
         if self._plan is not None:
             self._g_audio.copy_(audio)
             self._g_gt.copy_(gt)
             _lib.replay(self._plan)
+            self.engine.weights_dirty, self.engine.s2_fresh = self._post_flags
             return self._g_out
         if self._plan_after is not None and self._calls > self._plan_after and self._ready:
             self._g_audio, self._g_gt = audio.clone(), gt.contiguous().float().clone()
@@ -483,11 +525,14 @@ class FusedTrainer:
                 self._plan = _lib.RECORD
             finally:
                 _lib.RECORD = None
+            self.engine.pin_buffers()                    # the plan holds raw pointers into this shape's buffer set
+            self._post_flags = (self.engine.weights_dirty, self.engine.s2_fresh)
             return self._g_out
         if self._graph is not None:
             self._g_audio.copy_(audio)
             self._g_gt.copy_(gt)
             self._graph.replay()
+            self.engine.weights_dirty, self.engine.s2_fresh = self._post_flags
             return self._g_out
         if self._graph_after is not None and self._calls > self._graph_after and self._ready:
             self._g_audio, self._g_gt = audio.clone(), gt.contiguous().float().clone()
@@ -495,6 +540,8 @@ class FusedTrainer:
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
                 self._g_out = self._step_impl(self._g_audio, self._g_gt)
+            self.engine.pin_buffers()                    # the graph holds raw pointers into this shape's buffer set
+            self._post_flags = (self.engine.weights_dirty, self.engine.s2_fresh)
             self._graph.replay()            # capture only records: run the step once for real
             return self._g_out
         return self._step_impl(audio, gt)

@@ -26,10 +26,64 @@ class FlatParamEngine:
         self.flat_w16 = None
         self.param_meta = []                        # (param, offset, numel)
         self._shape_key = None
+        self._shape_sets = {}                       # shape key -> per-shape buffer set (see _shape_enter)
         self._packed_version = None
         self.weights_dirty = True
         self.s2_fresh = False
         self.on_grad_ready = None                   # callback(offset_lo): flat_g[offset_lo:] is final
+
+    # ------------------------------------------------------------------ per-shape buffer sets
+    # A captured hipGraph / launch plan holds raw device pointers into the engine's activation, workspace and
+    # packed-weight buffers.  Those buffers are therefore never freed when another input shape comes along (a ragged
+    # last validation batch between two graph replays): every shape key owns its own buffer set, kept alive in
+    # ``_shape_sets`` and swapped in O(1).  Everything an engine assigns in its _prepare*() is per-shape state;
+    # the names below are the shape-independent ones.
+    _SHAPE_INDEPENDENT = frozenset((
+        'module', 'dtype', 'model_name', 'depth_norm', 'n', 'levels', '_build', '_saved', 'flat_p', 'flat_g', 'flat_w16',
+        'param_meta', 'total', 'offset', 'on_grad_ready', '_shape_key', '_shape_sets', '_packed_version',
+        'weights_dirty', 's2_fresh', 'train_offset', 'step_counter', 'dropout_seed'))
+    MAX_SHAPE_SETS = 4
+
+    def _shape_snapshot(self):
+        snap = {k: v for k, v in self.__dict__.items() if k not in self._SHAPE_INDEPENDENT}
+        if isinstance(getattr(self, 'levels', None), list):          # U-Net: per-level dicts are updated in place
+            snap['__levels__'] = [dict(lv) for lv in self.levels]
+        return snap
+
+    def _shape_restore(self, snap):
+        for k, v in snap.items():
+            if k == '__levels__':
+                for lv, saved in zip(self.levels, v):
+                    lv.clear()
+                    lv.update(saved)
+            else:
+                self.__dict__[k] = v
+
+    def _shape_enter(self, key):
+        """Make ``key`` the current shape.  Returns True when its buffer set was restored from the cache (nothing to
+        build); False when the caller has to build it (the previous set has been parked, not freed)."""
+        if key == self._shape_key:
+            return True
+        if self._shape_key is not None:
+            self._shape_sets[self._shape_key] = self._shape_snapshot()
+            while len(self._shape_sets) > self.MAX_SHAPE_SETS:       # oldest first; pinned sets are never dropped
+                victim = next((k for k, v in self._shape_sets.items() if not v.get('_pinned')), None)
+                if victim is None:
+                    break
+                del self._shape_sets[victim]
+        snap = self._shape_sets.pop(key, None)
+        if snap is None:
+            self._pinned = False
+            self._shape_key = None         # a build that raises leaves no half-built current set behind
+            return False
+        self._shape_restore(snap)
+        self._shape_key = key
+        self.weights_dirty = True          # the packed operands of this set date from its last use
+        return True
+
+    def pin_buffers(self):
+        """Called by a graph / launch-plan capture: the current shape's buffer set must outlive the engine's use of it."""
+        self._pinned = True
 
     def _bound(self):
         if self.flat_p is None:
@@ -65,6 +119,7 @@ class FlatParamEngine:
         self.weights_dirty = True
         self.s2_fresh = False
         self._shape_key = None
+        self._shape_sets = {}              # views into the old flat buffers: rebuilt on demand
 
     @staticmethod
     def _view(flat, off, p):
@@ -83,3 +138,8 @@ class FlatParamEngine:
 
     def _version_sum(self):
         return sum(p._version for p, _, _ in self.param_meta)
+
+    def _mirror_fresh(self):
+        """True when the bf16 parameter mirror written by the fused optimizer still matches the f32 masters: nobody
+        (load_state_dict, an in-place edit) touched the parameters since the last pack."""
+        return self.s2_fresh and self._packed_version == self._version_sum()

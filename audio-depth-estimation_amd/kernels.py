@@ -280,6 +280,43 @@ def convt_n1_forward(dtype, B, Hs, Ws, in0, in1, w_master, bias, final_act, out,
         _prof_end(ev, 'convt_n1', 2.0 * B * Hs * Ws * 16 * cin)
 
 
+def l0_forward(x, w_master, B, Hs, Ws, slope, out_leaky, out_relu):
+    """First conv (2 -> 64 channels) of the bf16 path: x f32 NCHW [B,2,2Hs,2Ws], w f32 [64][16][2] (parameter memory)."""
+    _dev(x, w_master, out_leaky, out_relu)
+    _lib.call('adn_l0_forward', ptr(x), ptr(w_master), B, Hs, Ws, x.shape[1], w_master.numel() // (16 * x.shape[1]),
+              float(slope), ptr(out_leaky), ptr(out_relu), _stream())
+    _lib.annotate(label='edge', flops=2.0 * B * Hs * Ws * 64 * 16 * x.shape[1])
+
+
+def d0_dgrad_num_partials(B, Hs, Ws):
+    return _lib.load().adn_d0_dgrad_num_partials(B, Hs, Ws)
+
+
+def d0_dgrad(dz, w_master, B, Hs, Ws, seg0, seg1):
+    """Input gradient of the last transposed conv (128 -> 1): dz f32 [B,1,2Hs,2Ws], segments = skip / up half."""
+    _dev(dz, w_master)
+    s0, s1 = AdnEpiSeg(), AdnEpiSeg()
+    seg0.fill(s0)
+    seg1.fill(s1)
+    _lib.call('adn_d0_dgrad', ptr(dz), ptr(w_master), B, Hs, Ws, C.byref(s0), C.byref(s1), _stream())
+    _lib.annotate(label='edge', flops=2.0 * B * Hs * Ws * 128 * 16)
+
+
+def thin_wgrad_workspace_bytes(B, Hs, Ws, ct, c0, c1):
+    return _lib.load().adn_thin_wgrad_workspace_bytes(B, Hs, Ws, ct, c0, c1)
+
+
+def thin_wgrad(thin, plain0, plain1, B, Hs, Ws, dw, workspace):
+    """dw[c][tap*ct + t] = sum plain[.., c] * thin window; thin f32 [B,ct,2Hs,2Ws] planar, plain bf16 NHWC."""
+    _dev(thin, plain0, plain1, dw, workspace)
+    ct = thin.shape[1]
+    c0 = plain0.shape[-1]
+    c1 = plain1.shape[-1] if plain1 is not None else 0
+    _lib.call('adn_thin_wgrad', ptr(thin), ct, ptr(plain0), c0, ptr(plain1), c1, B, Hs, Ws, ptr(dw), ptr(workspace),
+              workspace.numel() * workspace.element_size(), _stream())
+    _lib.annotate(label='edge', flops=2.0 * B * Hs * Ws * (c0 + c1) * 16 * ct)
+
+
 def sum_to_scalar(x, out, workspace):
     _dev(x, out, workspace)
     _lib.call('adn_sum_to_scalar', ptr(x), x.numel(), dtype_code(x.dtype), ptr(out), ptr(workspace),
@@ -300,9 +337,10 @@ def optimizer_step(params, grads, exp_avg, exp_avg_sq, kind, lr, beta1, beta2, e
 
 
 def pack_t2_multi(flat_master, table, layers, total_blocks, dtype, t2_base):
+    """flat_master: the f32 masters or their bf16 mirror (same offsets)."""
     _dev(flat_master, table, t2_base)
-    _lib.call('adn_pack_t2_multi', ptr(flat_master), ptr(table), layers, total_blocks, dtype_code(dtype), ptr(t2_base),
-              _stream())
+    _lib.call('adn_pack_t2_multi', ptr(flat_master), dtype_code(flat_master.dtype), ptr(table), layers, total_blocks,
+              dtype_code(dtype), ptr(t2_base), _stream())
 
 
 def compute_errors(gt, pred, out7):

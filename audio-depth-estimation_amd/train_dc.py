@@ -97,6 +97,12 @@ def _device(args, local=None):
 
 
 def _loaders(cfg, args, kind, rank=0, world=1):
+    """(train loader, val loader, sampler, batched device front-end or None).
+
+    Real datasets are built with ``frontend='raw'``: DataLoader workers only read files (a forked worker must never
+    touch the HIP device the parent has initialised); the STFT / mel / resize of the whole batch runs in the parent
+    through GpuAudioFrontend, inside the step and forward lambdas (what train.py does too)."""
+    fe = None
     if args.synthetic:
         S, md = cfg.dataset.images_size, cfg.dataset.max_depth
         train, val = SyntheticDepthItems(args.synthetic, S, md, kind), SyntheticDepthItems(max(1, args.synthetic // 4), S, md, kind)
@@ -105,28 +111,41 @@ def _loaders(cfg, args, kind, rank=0, world=1):
         if kind == 'both':
             raise NotImplementedError('the (audio, image, depth) dataset variant needs OpenCV for the camera frames; '
                                       'use --synthetic in this image')
+        from .dataloader.utils_dataset import GpuAudioFrontend
         if cfg.dataset.name == 'batvisionv1':
             from .dataloader.BatvisionV1_Dataset import BatvisionV1Dataset as DS
-            train, val = DS(cfg, cfg.dataset.annotation_file_train), DS(cfg, cfg.dataset.annotation_file_val)
+            train = DS(cfg, cfg.dataset.annotation_file_train, frontend='raw')
+            val = DS(cfg, cfg.dataset.annotation_file_val, frontend='raw')
+            mode = 'bv1'
         else:
             from .dataloader.BatvisionV2_Dataset import BatvisionV2Dataset as DS
             img = kind == 'rgb'
-            train = DS(cfg, cfg.dataset.annotation_file_train, use_image=img)
-            val = DS(cfg, cfg.dataset.annotation_file_val, use_image=img)
+            train = DS(cfg, cfg.dataset.annotation_file_train, use_image=img, frontend='raw')
+            val = DS(cfg, cfg.dataset.annotation_file_val, use_image=img, frontend='raw')
+            mode = 'mel_spectrogram' if 'mel' in cfg.dataset.audio_format else 'spectrogram'
+        if kind == 'audio' and 'waveform' not in cfg.dataset.audio_format:
+            fe = GpuAudioFrontend(mode, cfg.dataset.images_size)
         workers = args.num_workers
     sampler = torch.utils.data.distributed.DistributedSampler(train, world, rank, shuffle=True) if world > 1 else None
     tl = DataLoader(train, batch_size=args.batch_size, shuffle=sampler is None, sampler=sampler, num_workers=workers,
                     pin_memory=True, drop_last=True)
     vl = DataLoader(val, batch_size=args.batch_size, shuffle=False, num_workers=workers, pin_memory=True)
-    return tl, vl, sampler
+    return tl, vl, sampler, fe
 
 
-def _validate(model, loader, dev, forward):
+def _to_device(batch, dev, fe):
+    batch = [t.to(dev, non_blocking=True) for t in batch]
+    if fe is not None:
+        batch[0] = fe(batch[0])            # raw waveforms [B,2,T] -> network input [B,2,S,S], one libadn call per batch
+    return batch
+
+
+def _validate(model, loader, dev, forward, fe=None):
     model.eval()
     errs = {k: [] for k in ('abs_rel', 'rmse', 'delta1', 'delta2', 'delta3')}
     with torch.no_grad():
         for batch in loader:
-            batch = [t.to(dev) for t in batch]
+            batch = _to_device(batch, dev, fe)
             pred = forward(model, batch)
             abs_rel, rmse, d1, d2, d3, _, _ = compute_errors(batch[-1], pred)
             for k, v in zip(errs, (abs_rel, rmse, d1, d2, d3)):
@@ -142,24 +161,28 @@ def _run(args, cfg, model, trainer, kind, step, forward, exp, ckpt_root='checkpo
     torch.manual_seed(args.seed)
     model.compute_dtype = torch.bfloat16 if args.precision == 'bf16' else torch.float32
     model = model.to(dev).train()
-    tl, vl, sampler = _loaders(cfg, args, kind, rank, world)
+    tl, vl, sampler, fe = _loaders(cfg, args, kind, rank, world)
     ckpt_dir = os.path.join(ckpt_root, exp)
     os.makedirs(ckpt_dir, exist_ok=True)
     say = print if rank == 0 else (lambda *a, **k: None)
-    start = 0
+    start, ck = 0, None
     if args.checkpoints:
         path = os.path.join(ckpt_dir, ckpt_fmt.format(args.checkpoints))
         if os.path.exists(path):
             ck = torch.load(path, map_location=dev)
             model.load_state_dict(ck['model_state_dict'])
-            if isinstance(ck.get('optimizer_state_dict'), dict) and 'exp_avg' in ck['optimizer_state_dict']:
-                trainer.load_state_dict(ck['optimizer_state_dict'], dev)
             start = ck['epoch']
             say(f'Loaded checkpoint from epoch {start}')
-    if reducer is not None:                                  # replicate rank 0's weights once (DataParallel.replicate)
-        eng = model.engine()
+    # Order matters under the reducer: bind the flat buffers ONCE, replicate rank 0's weights (DataParallel.replicate),
+    # and only then restore the optimizer state -- a second bind_parameters() would re-allocate flat_p / flat_g, make
+    # the trainer re-run its setup (zeroing the restored Adam moments) and leave the reducer on the stale gradients.
+    eng = model.engine()
+    if not eng._bound():
         eng.bind_parameters()
+    if reducer is not None:
         reducer.broadcast_parameters(eng.flat_p)
+    if ck is not None and isinstance(ck.get('optimizer_state_dict'), dict):
+        trainer.load_state_dict(ck['optimizer_state_dict'], dev)
     best = float('inf')
     eta_min = getattr(args, 'eta_min', 0.0)
     for epoch in range(start, args.nb_epochs):
@@ -170,12 +193,12 @@ def _run(args, cfg, model, trainer, kind, step, forward, exp, ckpt_root='checkpo
             sampler.set_epoch(epoch)
         t0, losses = time.time(), []
         for i, batch in enumerate(tl):
-            loss = step(trainer, [t.to(dev, non_blocking=True) for t in batch])
+            loss = step(trainer, _to_device(batch, dev, fe))
             losses.append(loss.detach().clone())
             if (i + 1) % 10 == 0:
                 say(f'Epoch [{epoch + 1}/{args.nb_epochs}] Batch [{i + 1}/{len(tl)}] Loss: {losses[-1].item():.4f}')
         train_loss = torch.stack(losses).mean().item() if losses else float('nan')
-        errs = _validate(model, vl, dev, forward)
+        errs = _validate(model, vl, dev, forward, fe)
         say(f'Epoch [{epoch + 1}/{args.nb_epochs}] train loss {train_loss:.4f}  val RMSE {errs["rmse"]:.4f} '
               f'ABS_REL {errs["abs_rel"]:.4f} Delta1 {errs["delta1"]:.4f}  lr {trainer.lr:.2e}  {time.time() - t0:.1f}s')
         state = {'epoch': epoch + 1, 'model_state_dict': model.state_dict(), 'optimizer_state_dict': trainer.state_dict(),

@@ -380,6 +380,29 @@ int adn_convt_n1_forward(int32_t dtype, int32_t B, int32_t Hs, int32_t Ws, const
                          const void* in1, int32_t C1, const float* w, const float* bias,
                          int32_t final_act, float* out, void* workspace, int64_t workspace_bytes,
                          void* stream);
+/* Thin outermost layers of unet_256 on the bf16 path (csrc/edge.hip): HBM-bound kernels, one MFMA per 16 pixels, the
+ * thin operand read as planar f32 and rounded to bf16 in registers (replace the channel-padded adn_igemm / adn_wgrad
+ * calls of the first Conv2d(2->64,k4,s2,p1) and the last ConvTranspose2d(128->1,k4,s2,p1),
+ * unetbaseline_model.py:187-198).
+ * adn_l0_forward: x f32 [B][2][2Hs][2Ws] (the network input, NCHW), w f32 [64][16][2] (parameter memory,
+ *   channels_last), outputs bf16 [B][Hs][Ws][64]: leaky (slope) and / or relu copy of the conv result.  Ws % 16 == 0. */
+int adn_l0_forward(const float* x, const float* w, int32_t B, int32_t Hs, int32_t Ws, int32_t cin,
+                   int32_t cout, float slope, void* out_leaky, void* out_relu, void* stream);
+/* adn_d0_dgrad: dz f32 [B][2Hs][2Ws] (gradient of the 1-channel output before the final activation), w f32 [128][16]
+ *   ([Cin][kh][kw][1]); seg0 / seg1 = skip / up half of the 128 input channels (64 each, bf16 NHWC): out0 = dIn masked
+ *   by ref > 0 (else * slope); seg1 may carry BatchNorm-backward statistics (z, mean, istd, partials: one row of
+ *   [2][64] per workgroup, adn_d0_dgrad_num_partials rows).  Ws % 16 == 0. */
+int64_t adn_d0_dgrad_num_partials(int32_t B, int32_t Hs, int32_t Ws);
+int adn_d0_dgrad(const float* dz, const float* w, int32_t B, int32_t Hs, int32_t Ws, const AdnEpiSeg* seg0,
+                 const AdnEpiSeg* seg1, void* stream);
+/* adn_thin_wgrad: dw[c][tap*ct_n + ct] = sum over pixels plain[b,i,j,c] * thin[b,ct,2i-1+kh,2j-1+kw]; thin f32
+ *   [B][ct_n][2Hs][2Ws], plain0 / plain1 bf16 [B][Hs][Ws][c0 | c1].  (ct_n, c0, c1) = (1, 64, 64): weight gradient of the
+ *   last transposed conv (thin = dz); (2, 64, 0): of the first conv (plain = its output gradient, thin = the network
+ *   input).  Deterministic (per-workgroup slabs in the workspace + fixed-order sum).  Ws % 32 == 0. */
+int64_t adn_thin_wgrad_workspace_bytes(int32_t B, int32_t Hs, int32_t Ws, int32_t ct_n, int32_t c0, int32_t c1);
+int adn_thin_wgrad(const float* thin, int32_t ct_n, const void* plain0, int32_t c0, const void* plain1,
+                   int32_t c1, int32_t B, int32_t Hs, int32_t Ws, float* dw, void* workspace,
+                   int64_t workspace_bytes, void* stream);
 /* sum over n f32/dtype elements into one f32 (bias gradient of the outermost ConvTranspose2d). */
 int adn_sum_to_scalar(const void* x, int64_t n, int32_t dtype, float* out, void* workspace,
                       int64_t workspace_bytes, void* stream);
@@ -397,9 +420,11 @@ int adn_optimizer_step(float* params, const float* grads, float* exp_avg, float*
                        float weight_decay, int32_t use_clip, double* state, void* bf16_copy,
                        void* stream);
 /* All T2 (phase-split) weight packs of a network in ONE launch.  table (device, int64 [L][5]):
- * master offset (floats) into flat_master, X, Y, t2 offset (elements) into t2_base, first block index;
- * total_blocks = sum over layers of ceil(X/64)*ceil(Y/64)*16. */
-int adn_pack_t2_multi(const float* flat_master, const int64_t* table, int32_t layers,
+ * master offset (elements) into flat_master, X, Y, t2 offset (elements) into t2_base, first block index;
+ * total_blocks = sum over layers of ceil(X/64)*ceil(Y/64)*16.  flat_master holds the parameters in
+ * master_dtype: ADN_F32 (the f32 masters) or ADN_BF16 (the bf16 mirror adn_optimizer_step keeps, same
+ * offsets: half the read traffic, identical values since bf16(master) is what the mirror stores). */
+int adn_pack_t2_multi(const void* flat_master, int32_t master_dtype, const int64_t* table, int32_t layers,
                       int64_t total_blocks, int32_t dtype, void* t2_base, void* stream);
 
 /* Evaluation metrics (compute_errors, utils_criterion.py:6-90), one set of 7 floats per sample:

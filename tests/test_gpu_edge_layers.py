@@ -119,3 +119,106 @@ def test_narrow_channel_counts_on_mfma(dtype):
         _, wst = ws_for(dtype, 1, B, 2 * Hs, 2 * Hs, Cin, 0, N, [N])
         k.igemm(dtype, 1, B, 2 * Hs, 2 * Hs, nhwc(x, dtype), None, t2b, N, 0, [k.Seg(N, out0=outt)], wst)
         assert rel_err(from_nhwc(outt), reft) <= TOL_F32_OUT[dtype]
+
+
+# ---- dedicated bf16 kernels of the thin layers (csrc/edge.hip): planar f32 thin operand, one MFMA per 16 pixels ----
+BF = torch.bfloat16
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 32), (3, 8, 16), (1, 64, 64)])
+def test_l0_forward_kernel(shape):
+    """First conv 2 -> 64 (unetbaseline_model.py:187-191 outermost downconv): leaky + relu copies, all borders."""
+    k = K()
+    B, Hs, Ws = shape
+    torch.manual_seed(21)
+    x = torch.randn(B, 2, 2 * Hs, 2 * Ws)
+    w = rounded(torch.randn(64, 2, 4, 4) * 0.1, BF)
+    ref = F.conv2d(rounded(x, BF), w, stride=2, padding=1)
+    master = w.permute(0, 2, 3, 1).contiguous().to(DEV)                # [64][kh][kw][2] = parameter memory
+    lk = torch.empty(B, Hs, Ws, 64, dtype=BF, device=DEV)
+    rl = torch.empty_like(lk)
+    k.l0_forward(x.to(DEV), master, B, Hs, Ws, 0.2, lk, rl)
+    assert rel_err(from_nhwc(lk), F.leaky_relu(ref, 0.2)) <= TOL_T_OUT[BF]
+    assert rel_err(from_nhwc(rl), F.relu(ref)) <= TOL_T_OUT[BF]
+    k.l0_forward(x.to(DEV), master, B, Hs, Ws, 0.2, None, rl)          # a single output is allowed
+    assert rel_err(from_nhwc(rl), F.relu(ref)) <= TOL_T_OUT[BF]
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 32), (3, 8, 16), (1, 64, 64)])
+@pytest.mark.parametrize('stats', [True, False])
+def test_d0_dgrad_kernel(shape, stats):
+    """Input gradient of the last transposed conv 128 -> 1: ReLU masks of both halves + BN-backward sums of the up half."""
+    k = K()
+    B, Hs, Ws = shape
+    torch.manual_seed(22)
+    dz = torch.randn(B, 1, 2 * Hs, 2 * Ws)
+    wt = rounded(torch.randn(128, 1, 4, 4) * 0.05, BF)
+    dA = F.conv2d(rounded(dz, BF), wt, stride=2, padding=1)              # [B,128,Hs,Ws]
+    master = wt.permute(0, 2, 3, 1).contiguous().view(-1).to(DEV)       # [128][16]
+    ref0 = rounded(torch.randn(B, 64, Hs, Ws), BF)
+    ref1 = rounded(torch.randn(B, 64, Hs, Ws), BF)
+    z1 = rounded(torch.randn(B, 64, Hs, Ws), BF)
+    mean, istd = torch.randn(64) * 0.1, torch.rand(64) + 0.5
+    g0 = dA[:, :64] * (ref0 > 0)
+    g1 = dA[:, 64:] * (ref1 > 0)
+    o0 = torch.empty(B, Hs, Ws, 64, dtype=BF, device=DEV)
+    o1 = torch.empty_like(o0)
+    P = k.d0_dgrad_num_partials(B, Hs, Ws)
+    part = torch.full((P, 2, 64), float('nan'), device=DEV)
+    s0 = k.Seg(64, out0=o0, ref=nhwc(ref0, BF), slope=0.0)
+    if stats:
+        s1 = k.Seg(64, out0=o1, ref=nhwc(ref1, BF), slope=0.0, z=nhwc(z1, BF), mean=mean.to(DEV), istd=istd.to(DEV),
+                   partials=part)
+    else:
+        s1 = k.Seg(64, out0=o1, ref=nhwc(ref1, BF), slope=0.0)
+    k.d0_dgrad(dz.to(DEV), master, B, Hs, Ws, s0, s1)
+    assert rel_err(from_nhwc(o0), g0) <= TOL_T_OUT[BF]
+    assert rel_err(from_nhwc(o1), g1) <= TOL_T_OUT[BF]
+    if stats:
+        tot = part.sum(0).cpu()
+        xh = (z1 - mean.view(1, -1, 1, 1)) * istd.view(1, -1, 1, 1)
+        assert rel_err(tot[0], g1.sum((0, 2, 3))) <= 1e-3
+        assert rel_err(tot[1], (g1 * xh).sum((0, 2, 3))) <= 1e-3
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 32), (3, 8, 32), (1, 64, 64)])
+def test_thin_wgrad_kernels(shape):
+    """Weight gradients against the thin operand: last transposed conv (thin = dz) and first conv (thin = input)."""
+    k = K()
+    B, Hs, Ws = shape
+    torch.manual_seed(23)
+    # (a) ConvTranspose2d 128 -> 1: dW[c][kh][kw] = sum in[b,c,i,j] * dz[b,0,2i-1+kh,2j-1+kw]
+    a = rounded(torch.randn(B, 128, Hs, Ws), BF)
+    dz = torch.randn(B, 1, 2 * Hs, 2 * Ws)
+    wz = torch.zeros(128, 1, 4, 4, requires_grad=True)
+    F.conv_transpose2d(a, wz, stride=2, padding=1).backward(rounded(dz, BF))
+    refw = wz.grad.permute(0, 2, 3, 1).reshape(128, 16)
+    dw = torch.full((128, 16), float('nan'), device=DEV)
+    ws = torch.empty(k.thin_wgrad_workspace_bytes(B, Hs, Ws, 1, 64, 64) // 4, device=DEV)
+    k.thin_wgrad(dz.to(DEV), nhwc(a[:, :64], BF), nhwc(a[:, 64:], BF), B, Hs, Ws, dw, ws)
+    assert rel_err(dw, refw) <= TOL_F32_OUT[BF]
+    dw2 = torch.empty_like(dw)
+    k.thin_wgrad(dz.to(DEV), nhwc(a[:, :64], BF), nhwc(a[:, 64:], BF), B, Hs, Ws, dw2, ws)
+    assert torch.equal(dw, dw2)                                          # fixed-order sums: bit-reproducible
+    # (b) Conv2d 2 -> 64: dW[o][kh][kw][ci] = sum g[b,o,oy,ox] * x[b,ci,2oy-1+kh,2ox-1+kw]
+    x = torch.randn(B, 2, 2 * Hs, 2 * Ws)
+    g = rounded(torch.randn(B, 64, Hs, Ws), BF)
+    wc = torch.zeros(64, 2, 4, 4, requires_grad=True)
+    F.conv2d(rounded(x, BF), wc, stride=2, padding=1).backward(g)
+    refc = wc.grad.permute(0, 2, 3, 1).reshape(64, 32)
+    dwc = torch.full((64, 32), float('nan'), device=DEV)
+    ws2 = torch.empty(k.thin_wgrad_workspace_bytes(B, Hs, Ws, 2, 64, 0) // 4, device=DEV)
+    k.thin_wgrad(x.to(DEV), nhwc(g, BF), None, B, Hs, Ws, dwc, ws2)
+    assert rel_err(dwc, refc) <= TOL_F32_OUT[BF]
+
+
+def test_edge_kernels_reject_other_shapes():
+    k = K()
+    x = torch.zeros(1, 3, 32, 32, device=DEV)
+    w = torch.zeros(64 * 16 * 3, device=DEV)
+    o = torch.empty(1, 16, 16, 64, dtype=BF, device=DEV)
+    with pytest.raises(RuntimeError, match='2 -> 64'):
+        k.l0_forward(x, w, 1, 16, 16, 0.2, o, None)
+    with pytest.raises(RuntimeError, match='Ws % 16'):
+        k.l0_forward(torch.zeros(1, 2, 16, 16, device=DEV), torch.zeros(2048, device=DEV), 1, 8, 8, 0.2,
+                     torch.empty(1, 8, 8, 64, dtype=BF, device=DEV), None)
