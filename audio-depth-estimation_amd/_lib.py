@@ -139,6 +139,11 @@ _PROTOS = {
     'adn_bn_fwd_finalize': (C.c_int, [c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p, c_float, c_float,
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p]),
+    'adn_bn_fwd_fused': (C.c_int, [c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p,
+                                   c_void_p, c_void_p]),
+    'adn_bn_bwd_fused': (C.c_int, [c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
+                                   c_void_p, c_void_p, c_void_p, c_void_p]),
     'adn_bn_eval_affine': (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int32, c_void_p, c_void_p,
                                      c_void_p]),
     'adn_bn_act': (C.c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_float, c_void_p, c_void_p,

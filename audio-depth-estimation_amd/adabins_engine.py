@@ -391,19 +391,36 @@ class AdaBinsTrainer(GraphedStep):
             raise RuntimeError('the hipGraph step is not combined with the data-parallel reducer (host-side collectives)')
         super().enable_graph(after_steps)
 
+    def _optim_meta(self):
+        """Parameters the reference's optimizer holds: filter(requires_grad, model.parameters())
+        (train_adabins_distillation.py:371-386); the teacher's (never given a gradient) carry no state."""
+        return [(p, off, n) for p, off, n in self.engine.param_meta if p.requires_grad]
+
     def state_dict(self):
-        """Optimizer state (flat Adam moments + step counter) for the checkpoint's 'optimizer_state_dict' entry."""
-        if not self._ready:
-            return {'kind': self.opt_kind, 'lr': self.lr, 'step': 0}
-        return {'kind': self.opt_kind, 'lr': self.lr, 'betas': self.betas, 'eps': self.eps,
-                'weight_decay': self.weight_decay, 'step': int(self.state[0].item()),
-                'exp_avg': self.exp_avg.detach().cpu(), 'exp_avg_sq': self.exp_avg_sq.detach().cpu()}
+        """'optimizer_state_dict' in torch.optim format (optim_state.py)."""
+        from . import optim_state
+        eng = self.engine
+        if not eng._bound():
+            eng.bind_parameters()
+        step = int(self.state[0].item()) if self._ready else 0
+        sd = optim_state.export_state(self._optim_meta(), eng._view, self.exp_avg if self._ready else None,
+                                      self.exp_avg_sq if self._ready else None, step, self.opt_kind, self.lr, self.betas,
+                                      self.eps, self.weight_decay)
+        for i, (p, off, _) in enumerate(self._optim_meta()):          # teacher parameters: no gradient, no state
+            if off < eng.train_offset:
+                sd['state'].pop(i, None)
+        return sd
 
     def load_state_dict(self, sd, device):
+        from . import optim_state
         if not self.engine._bound():
             self.engine.bind_parameters()
         self._setup(device)
-        if 'exp_avg' in sd:
+        if optim_state.is_torch_format(sd):
+            step, group = optim_state.import_state(sd, self._optim_meta(), self.engine._view, self.exp_avg, self.exp_avg_sq)
+            self.state[0] = float(step)
+            self.lr = float(group.get('lr', self.lr))
+        elif 'exp_avg' in sd:
             self.exp_avg.copy_(sd['exp_avg'])
             self.exp_avg_sq.copy_(sd['exp_avg_sq'])
             self.state[0] = float(sd['step'])

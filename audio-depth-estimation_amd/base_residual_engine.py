@@ -30,9 +30,10 @@ class BaseResidualEngine(DCEngine):
         if Cin != m.input_channels:
             raise RuntimeError(f'expected input[{B}, {Cin}, {H}, {W}] to have {m.input_channels} channels, but got {Cin} '
                                'channels instead')
-        if H != m.output_size or W != m.output_size:
-            raise NotImplementedError(f'input {H}x{W} != output_size {m.output_size}: the final bilinear resize (reference '
-                                      ':176-179) is not on the libadn path')
+        # input size != output_size: both heads resize their ACTIVATED map (bilinear, align_corners=False) before the sum
+        # and the clamp (base_residual_model.py:185-211)
+        S = m.output_size
+        osz = S if (H != S or W != S) else None
         self.B, self.dev = B, x.device
         self._scratch = {}
         self.epc = 8 if self.dtype == torch.bfloat16 else 4
@@ -53,8 +54,8 @@ class BaseResidualEngine(DCEngine):
                 ops += o
             ends[tag] = d
         self.inputs, self.ops = [(inp, 0, Cin)], ops
-        self.head_base = Head1x1(ends['base'], m.base_head, 1, m.max_depth)              # sigmoid * max_depth
-        self.head_res = Head1x1(ends['res'], m.res_head, 2, 0.3 * m.max_depth)           # tanh * 0.3 * max_depth
+        self.head_base = Head1x1(ends['base'], m.base_head, 1, m.max_depth, osz, clamp_after_resize=False)   # sigmoid * max_depth
+        self.head_res = Head1x1(ends['res'], m.res_head, 2, 0.3 * m.max_depth, osz, clamp_after_resize=False)  # tanh * 0.3 max_depth
         acts = {}
         for op in ops:
             for a in list(getattr(op, 'srcs', [])) + [getattr(op, 'src', None), getattr(op, 'out', None)]:
@@ -69,7 +70,7 @@ class BaseResidualEngine(DCEngine):
             op.prepare(self)
             ws = max(ws, op.workspace_bytes(self))
         f32 = dict(dtype=torch.float32, device=x.device)
-        self.final = torch.empty(B, 1, H, W, **f32)
+        self.final = torch.empty(B, 1, S, S, **f32) if osz else torch.empty(B, 1, H, W, **f32)
         self.workspace = torch.empty(max(ws, K.lowpass_workspace_bytes(B, H, W, 64)) // 4 + 4, **f32)
         self.weights_dirty = True
         self._shape_key = key
@@ -112,9 +113,8 @@ class BaseResidualTrainer(GraphedStep):
     def __init__(self, engine, lambda_recon=1.0, lambda_base=1.2, lambda_sparse=0.05, lowpass_kernel=16, use_l1=True,
                  use_silog=False, silog_lambda=0.5, optimizer='AdamW', lr=1e-4, betas=(0.9, 0.999), eps=1e-8,
                  weight_decay=None, clip_norm=1.0, ddp=None):
-        if not use_silog and not use_l1:
-            raise NotImplementedError('the MSE reconstruction variant (use_l1=False, use_silog=False) is not implemented')
         self.engine = engine
+        self.use_l1 = use_l1
         self.lambda_recon, self.lambda_base, self.lambda_sparse = lambda_recon, lambda_base, lambda_sparse
         self.k, self.use_silog, self.silog_lambda = lowpass_kernel, use_silog, silog_lambda
         self.opt_kind = {'AdamW': 0, 'Adam': 1, 'SGD': 2}[optimizer]
@@ -141,12 +141,18 @@ class BaseResidualTrainer(GraphedStep):
         self.set_weights(c.lambda_recon, c.lambda_base)
 
     def load_state_dict(self, sd, device):
-        """Restore what state_dict() saved (flat Adam moments + step counter) -- the 'optimizer_state_dict' entry of the
-        checkpoints written by train_dc._run."""
+        """Restore a torch.optim state dict (optim_state.py; the 'optimizer_state_dict' entry of the checkpoints written
+        by train_dc._run or by the reference's torch optimizer); round 1's flat layout is still read."""
+        from . import optim_state
         if not self.engine._bound():
             self.engine.bind_parameters()
         self._setup_optimizer(torch.device(device))
-        if 'exp_avg' in sd:
+        if optim_state.is_torch_format(sd):
+            step, group = optim_state.import_state(sd, self.engine.param_meta, self.engine._view, self.exp_avg,
+                                                   self.exp_avg_sq)
+            self.state[0] = float(step)
+            self.lr = float(group.get('lr', self.lr))
+        elif 'exp_avg' in sd:
             self.exp_avg.copy_(sd['exp_avg'])
             self.exp_avg_sq.copy_(sd['exp_avg_sq'])
             self.state[0] = float(sd['step'])
@@ -177,11 +183,15 @@ class BaseResidualTrainer(GraphedStep):
         self._ready = True
 
     def state_dict(self):
-        if not self._ready:
-            return {'kind': self.opt_kind, 'lr': self.lr, 'step': 0}
-        return {'kind': self.opt_kind, 'lr': self.lr, 'betas': self.betas, 'eps': self.eps,
-                'weight_decay': self.weight_decay, 'step': int(self.state[0].item()),
-                'exp_avg': self.exp_avg.detach().cpu(), 'exp_avg_sq': self.exp_avg_sq.detach().cpu()}
+        from . import optim_state
+        eng = self.engine
+        if not eng._bound():
+            eng.bind_parameters()
+        ready = getattr(self, '_opt_ready', False)
+        step = int(self.state[0].item()) if ready else 0
+        return optim_state.export_state(eng.param_meta, eng._view, self.exp_avg if ready else None,
+                                        self.exp_avg_sq if ready else None, step, self.opt_kind, self.lr, self.betas,
+                                        self.eps, self.weight_decay)
 
     def step(self, x, gt):
         """Returns (total loss 0-dim device tensor, terms f32[4] = weighted recon, mean|base-struct|, mean|res|, total)."""
@@ -194,12 +204,13 @@ class BaseResidualTrainer(GraphedStep):
         if not self._ready or self.struct.shape != final.shape:
             self._setup(final)
         K.lowpass(gt, self.k, self.struct, eng.workspace)
-        crit = 2                                               # Combined with one active weight = weighted L1 or SIlog
+        from .utils_base_residual_loss import recon_criterion
+        crit, mm = recon_criterion(self.use_l1, self.use_silog)   # weighted SIlog / L1 (Combined, one weight) or masked MSE
         l1w, sw = (0.0, self.lambda_recon) if self.use_silog else (self.lambda_recon, 0.0)
-        K.loss_stats(final, gt, 1.0, 1, 1e-6, self.lstats, self.loss_ws)
+        K.loss_stats(final, gt, 1.0, mm, 1e-6, self.lstats, self.loss_ws)
         if self.ddp is not None:          # one global-batch loss, as under DataParallel (base_residual_model.py:266-269)
             self.ddp.all_reduce_loss_stats(self.lstats)
-        K.loss_finish(final, gt, 1.0, 1, 1e-6, self.lstats, crit, l1w, sw, self.silog_lambda, self.recon, self.gfinal)
+        K.loss_finish(final, gt, 1.0, mm, 1e-6, self.lstats, crit, l1w, sw, self.silog_lambda, self.recon, self.gfinal)
         K.baseres_stats(base, resid, self.struct, gt, self.recon, self.lambda_recon, self.lambda_base, self.lambda_sparse,
                         self.bstats, self.terms, eng.workspace)
         if self.ddp is not None:

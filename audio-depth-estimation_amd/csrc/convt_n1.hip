@@ -60,10 +60,12 @@ __global__ __launch_bounds__(256) void convt_n1_gather_kernel(const float* P, in
   const int Hl = 2 * Hs, Wl = 2 * Ws;
   const int64_t n = (int64_t)B * Hl * Wl;
   const float bv = bias ? bias[0] : 0.f;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
-    const int ox = (int)(e % Wl);
-    const int oy = (int)((e / Wl) % Hl);
-    const int b = (int)(e / ((int64_t)Wl * Hl));
+  // (32-bit index arithmetic: the host checks n < 2^31; a 64-bit division is a several-hundred-instruction routine)
+  for (unsigned e = blockIdx.x * 256 + threadIdx.x; e < (unsigned)n; e += gridDim.x * 256) {
+    const unsigned rowi = e / (unsigned)Wl;
+    const int ox = (int)(e - rowi * (unsigned)Wl);
+    const int b = (int)(rowi / (unsigned)Hl);
+    const int oy = (int)(rowi - (unsigned)b * Hl);
     const int ph = oy & 1, pw = ox & 1, i = oy >> 1, j = ox >> 1;
     float v = bv;
 #pragma unroll

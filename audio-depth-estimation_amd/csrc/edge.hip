@@ -34,20 +34,19 @@ __device__ __forceinline__ bf16x8_t as_frag(const u32x4_t& c) { return *reinterp
 // tile t (0..3 of a 64-channel segment), MFMA row a (0..15) -> channel inside the segment
 __device__ __forceinline__ int edge_ch(int t, int a) { return (t >> 1) * 32 + (a >> 2) * 8 + (t & 1) * 4 + (a & 3); }
 
-// Columns 2j-1 .. 2j+2 of one row of a planar f32 image for the 16 lanes (n = 0..15, pixel j = j0 + n) of a lane row:
-// every lane loads its aligned pair (2j, 2j+1); the outer two columns come from the neighbour lanes, the two lanes at
-// the ends of the lane row load theirs.  All 64 lanes must be active (cross-lane moves).
-__device__ __forceinline__ void window4(const float* rowp, bool row_ok, int j, int n, int Wl, float* w4) {
-  float2 own = make_float2(0.f, 0.f);
-  if (row_ok) own = *reinterpret_cast<const float2*>(rowp + 2 * j);
-  float left = __shfl_up(own.y, 1, 16);
-  float right = __shfl_down(own.x, 1, 16);
-  if (n == 0) left = (row_ok && j > 0) ? rowp[2 * j - 1] : 0.f;
-  if (n == 15) right = (row_ok && 2 * j + 2 < Wl) ? rowp[2 * j + 2] : 0.f;
-  w4[0] = left;
-  w4[1] = own.x;
-  w4[2] = own.y;
-  w4[3] = right;
+// Columns 2j-1 .. 2j+2 of one row of a planar f32 image: four independent dword loads (clamped addresses, zero by
+// select: no branch, so the loads of all rows of an iteration are in flight together; neighbouring lanes share the
+// cache lines).  rowp must point at a readable row even when row_ok is false.
+__device__ __forceinline__ void window4(const float* rowp, bool row_ok, int j, int Wl, float* w4) {
+  const int c = 2 * j - 1;
+  const float v0 = rowp[c < 0 ? 0 : c];
+  const float v1 = rowp[c + 1];
+  const float v2 = rowp[c + 2];
+  const float v3 = rowp[c + 3 < Wl ? c + 3 : Wl - 1];
+  w4[0] = (row_ok && c >= 0) ? v0 : 0.f;
+  w4[1] = row_ok ? v1 : 0.f;
+  w4[2] = row_ok ? v2 : 0.f;
+  w4[3] = (row_ok && c + 3 < Wl) ? v3 : 0.f;
 }
 
 __device__ __forceinline__ void store_bf16x8(uint16_t* p, const float* f) {
@@ -70,26 +69,31 @@ __global__ __launch_bounds__(256) void l0_fwd_kernel(const float* __restrict__ x
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const float* wp = w + edge_ch(t, n) * 32 + q * 8;          // k = ky*8 + kx*2 + ci, this lane: ky = q
-    u32x4_t c;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) c[i] = pk_bf16(wp[2 * i], wp[2 * i + 1]);
+    const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(wp), hi = *reinterpret_cast<const f32x4_t*>(wp + 4);
+    const u32x4_t c = {pk_bf16(lo[0], lo[1]), pk_bf16(lo[2], lo[3]), pk_bf16(hi[0], hi[1]), pk_bf16(hi[2], hi[3])};
     wf[t] = as_frag(c);
   }
+  // A wave's work unit is a run of 4 pixel groups of one output row: the row decode (32-bit divisions) and the row
+  // pointers are per unit, the inner loop over the 16-pixel groups only advances by constants (the kernel is VALU-issue bound, not HBM bound, when
+  // every group pays its own index arithmetic: 300 instructions per 16 pixels).
   const int gpr = Ws >> 4;
-  const int64_t groups = (int64_t)B * Hs * gpr;
-  for (int64_t g = (int64_t)blockIdx.x * 4 + wave; g < groups; g += (int64_t)gridDim.x * 4) {
-    const int jg = (int)(g % gpr);
-    const int64_t bi = g / gpr;
-    const int oy = (int)(bi % Hs);
-    const int b = (int)(bi / Hs);
+  const int gu = (gpr & 3) == 0 ? 4 : 1;                     // groups per work unit (a run of 64 pixels of one row)
+  const unsigned upr = (unsigned)(gpr / gu);
+  const unsigned units = (unsigned)B * Hs * upr;
+  for (unsigned u = blockIdx.x * 4 + wave; u < units; u += gridDim.x * 4) {
+    const unsigned bi = u / upr;
+    const int jg0 = (int)(u - bi * upr) * gu;
+    const int b = (int)(bi / (unsigned)Hs);
+    const int oy = (int)(bi - (unsigned)b * Hs);
+   for (int jg = jg0; jg < jg0 + gu; ++jg) {
     const int ox = jg * 16 + n;
     const int iy = 2 * oy - 1 + q;
     const bool rok = (unsigned)iy < (unsigned)Hl;
     const float* r0 = x + (((int64_t)b * 2) * Hl + (rok ? iy : 0)) * Wl;
     const float* r1 = r0 + (int64_t)Hl * Wl;
     float a0[4], a1[4];
-    window4(r0, rok, ox, n, Wl, a0);
-    window4(r1, rok, ox, n, Wl, a1);
+    window4(r0, rok, ox, Wl, a0);
+    window4(r1, rok, ox, Wl, a1);
     u32x4_t bc;
 #pragma unroll
     for (int kx = 0; kx < 4; ++kx) bc[kx] = pk_bf16(a0[kx], a1[kx]);
@@ -119,6 +123,7 @@ __global__ __launch_bounds__(256) void l0_fwd_kernel(const float* __restrict__ x
         store_bf16x8(out_relu + idx, o);
       }
     }
+   }
   }
 }
 
@@ -142,32 +147,47 @@ __global__ __launch_bounds__(256) void d0_dgrad_kernel(D0Params p) {
   for (int s = 0; s < 2; ++s)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      u32x4_t c = {0u, 0u, 0u, 0u};
-      if (q < 2) {                                                    // k = tap = 8q + j; k >= 16 is padding
-        const float* wp = p.w + (s * 64 + edge_ch(t, n)) * 16 + q * 8;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) c[i] = pk_bf16(wp[2 * i], wp[2 * i + 1]);
-      }
+      // k = tap = 8q + j; k >= 16 (q >= 2) is padding: loaded from a valid address and zeroed by select (no branch:
+      // the 8 fragment loads of a wave's prologue stay in flight together)
+      const float* wp = p.w + (s * 64 + edge_ch(t, n)) * 16 + (q & 1) * 8;
+      const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(wp), hi = *reinterpret_cast<const f32x4_t*>(wp + 4);
+      u32x4_t c = {pk_bf16(lo[0], lo[1]), pk_bf16(lo[2], lo[3]), pk_bf16(hi[0], hi[1]), pk_bf16(hi[2], hi[3])};
+      if (q >= 2) c = u32x4_t{0u, 0u, 0u, 0u};
       wf[s][t] = as_frag(c);
     }
   // BatchNorm-backward statistics of segment 1 (the up half: the skip half of the outermost level has no BatchNorm):
   // this lane's 16 channels (h*32 + q*8 + e), accumulated over its pixels
   const bool stats = p.seg[1].partials != nullptr;
   float mean[16], istd[16], s1[16], s2[16];
+  {
+    const float* mp = stats ? p.seg[1].mean : p.w;      // any readable 64 floats when there are no statistics
+    const float* ip = stats ? p.seg[1].istd : p.w;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const int c = (e >> 3) * 32 + q * 8 + (e & 7);
-    mean[e] = stats ? p.seg[1].mean[c] : 0.f;
-    istd[e] = stats ? p.seg[1].istd[c] : 0.f;
-    s1[e] = s2[e] = 0.f;
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int v4 = 0; v4 < 2; ++v4) {
+        const f32x4_t m4 = *reinterpret_cast<const f32x4_t*>(mp + h * 32 + q * 8 + v4 * 4);
+        const f32x4_t i4 = *reinterpret_cast<const f32x4_t*>(ip + h * 32 + q * 8 + v4 * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          mean[h * 8 + v4 * 4 + e] = m4[e];
+          istd[h * 8 + v4 * 4 + e] = i4[e];
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s1[e] = s2[e] = 0.f;
   }
   const int gpr = Ws >> 4;
-  const int64_t groups = (int64_t)p.B * Hs * gpr;
-  for (int64_t g = (int64_t)blockIdx.x * 4 + wave; g < groups; g += (int64_t)gridDim.x * 4) {
-    const int jg = (int)(g % gpr);
-    const int64_t bi = g / gpr;
-    const int i = (int)(bi % Hs);
-    const int b = (int)(bi / Hs);
+  const int gu = (gpr & 3) == 0 ? 4 : 1;                     // work unit = 4 pixel groups of one row (see l0_fwd)
+  const unsigned upr = (unsigned)(gpr / gu);
+  const unsigned units = (unsigned)p.B * Hs * upr;
+  for (unsigned u = blockIdx.x * 4 + wave; u < units; u += gridDim.x * 4) {
+    const unsigned bi = u / upr;
+    const int jg0 = (int)(u - bi * upr) * gu;
+    const int b = (int)(bi / (unsigned)Hs);
+    const int i = (int)(bi - (unsigned)b * Hs);
+   for (int jg = jg0; jg < jg0 + gu; ++jg) {
     const int j = jg * 16 + n;
     // B fragment: k = 8q + e, e = rr*4 + kx -> tap (ky = 2q + rr, kx): rows 2i-1+2q+rr
     u32x4_t bc = {0u, 0u, 0u, 0u};
@@ -177,8 +197,8 @@ __global__ __launch_bounds__(256) void d0_dgrad_kernel(D0Params p) {
       const bool ok0 = q < 2 && (unsigned)iy0 < (unsigned)Hl;
       const bool ok1 = q < 2 && (unsigned)(iy0 + 1) < (unsigned)Hl;
       const float* base = p.dz + (int64_t)b * Hl * Wl;
-      window4(base + (int64_t)(ok0 ? iy0 : 0) * Wl, ok0, j, n, Wl, w0);
-      window4(base + (int64_t)(ok1 ? iy0 + 1 : 0) * Wl, ok1, j, n, Wl, w1);
+      window4(base + (int64_t)(ok0 ? iy0 : 0) * Wl, ok0, j, Wl, w0);
+      window4(base + (int64_t)(ok1 ? iy0 + 1 : 0) * Wl, ok1, j, Wl, w1);
       bc[0] = pk_bf16(w0[0], w0[1]);
       bc[1] = pk_bf16(w0[2], w0[3]);
       bc[2] = pk_bf16(w1[0], w1[1]);
@@ -186,6 +206,19 @@ __global__ __launch_bounds__(256) void d0_dgrad_kernel(D0Params p) {
     }
     const bf16x8_t bfr = as_frag(bc);
     const int64_t pix = ((int64_t)b * Hs + i) * Ws + j;
+    // every epilogue operand of this pixel group is requested before the first use (6 x 16 bytes per lane in flight)
+    u32x4_t rraw[2][2], zraw[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        rraw[s][h] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const uint16_t*>(p.seg[s].ref) + pix * 64 + h * 32 +
+                                                       q * 8);
+    {
+      const uint16_t* zp = reinterpret_cast<const uint16_t*>(stats ? p.seg[1].z : p.seg[1].ref);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) zraw[h] = *reinterpret_cast<const u32x4_t*>(zp + pix * 64 + h * 32 + q * 8);
+    }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const AdnEpiSeg& sg = p.seg[s];
@@ -197,7 +230,7 @@ __global__ __launch_bounds__(256) void d0_dgrad_kernel(D0Params p) {
       for (int h = 0; h < 2; ++h) {
         const int64_t idx = pix * 64 + h * 32 + q * 8;
         float r[8], gq[8];
-        load_bf16x8(reinterpret_cast<const uint16_t*>(sg.ref) + idx, r);
+        Chunk<uint16_t>::unpack(rraw[s][h], r);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           gq[e] = acc[2 * h][e];
@@ -206,9 +239,9 @@ __global__ __launch_bounds__(256) void d0_dgrad_kernel(D0Params p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) gq[e] *= (r[e] > 0.f ? 1.0f : sg.slope);
         store_bf16x8(reinterpret_cast<uint16_t*>(sg.out0) + idx, gq);
-        if (s == 1 && stats) {
+        if (s == 1) {
           float z[8];
-          load_bf16x8(reinterpret_cast<const uint16_t*>(sg.z) + idx, z);
+          Chunk<uint16_t>::unpack(zraw[h], z);
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             s1[h * 8 + e] += gq[e];
@@ -217,6 +250,7 @@ __global__ __launch_bounds__(256) void d0_dgrad_kernel(D0Params p) {
         }
       }
     }
+   }
   }
   // statistics: sum over the 16 pixels of a lane row, then over the 4 waves, one partial row per workgroup
   if (stats) {                                   // kernel-uniform
@@ -271,12 +305,12 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(TWParams p) {
   const int n = lane & 15, q = lane >> 4;
   const int Hs = p.Hs, Ws = p.Ws, Hl = 2 * Hs, Wl = 2 * Ws;
   char* wbase = smem + wave * (2 * BUF);
-  const int spr = Ws >> 5;                                   // K-steps per image row
-  const int64_t steps = (int64_t)p.B * Hs * spr;
-  const int64_t stride = (int64_t)gridDim.x * 4;
+  const unsigned spr = (unsigned)Ws >> 5;                    // K-steps per image row
+  const unsigned steps = (unsigned)p.B * Hs * spr;          // (32-bit index arithmetic: no 64-bit divisions)
+  const unsigned stride = gridDim.x * 4;
 
-  auto dma = [&](int64_t s, int buf) {
-    const int64_t pix0 = s * 32;                           // rows are contiguous: step s starts at pixel 32*s
+  auto dma = [&](unsigned s, int buf) {
+    const int64_t pix0 = (int64_t)s * 32;                  // rows are contiguous: step s starts at pixel 32*s
     char* dst = wbase + buf * BUF;
     if constexpr (NT0 > 0) {
       constexpr int LPR = RB0 / 16, RPI = 64 / LPR, NI = 32 / RPI;
@@ -295,11 +329,11 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(TWParams p) {
     }
   };
   // thin fragment of M-tile m: lane (a = n, q) holds row 16m + a = (tap, ct), pixels j0 + 8q + jj (jj = 0..7)
-  auto load_thin = [&](int64_t s, float (*av)[8]) {
-    const int js = (int)(s % spr);
-    const int64_t bi = s / spr;
-    const int i = (int)(bi % Hs);
-    const int b = (int)(bi / Hs);
+  auto load_thin = [&](unsigned s, float (*av)[8]) {
+    const unsigned bi = s / spr;
+    const int js = (int)(s - bi * spr);
+    const int b = (int)(bi / (unsigned)Hs);
+    const int i = (int)(bi - (unsigned)b * Hs);
 #pragma unroll
     for (int m = 0; m < CT; ++m) {
       const int row = 16 * m + n;
@@ -323,7 +357,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(TWParams p) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[m][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  int64_t s = (int64_t)blockIdx.x * 4 + wave;
+  unsigned s = blockIdx.x * 4 + wave;
   float nxt[CT][8];
   if (s < steps) {
     dma(s, 0);
@@ -381,29 +415,42 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(TWParams p) {
     out[e] = (red[e] + red[ROWS * CTOT + e]) + (red[2 * ROWS * CTOT + e] + red[3 * ROWS * CTOT + e]);
 }
 
-// dW[c][row] = sum over workgroup slabs (fixed order: bit-reproducible)
+// dW[c][row] = sum over the workgroup slabs in a fixed order (bit-reproducible): a workgroup owns 16 consecutive
+// outputs, its 16 thread groups each sum every 16th slab, LDS combines the groups.
 __global__ __launch_bounds__(256) void thin_wgrad_sum_kernel(const float* slab, int nblk, int rows, int ctot, float* dw) {
-  const int e = blockIdx.x * 256 + threadIdx.x;              // e = row * ctot + c
-  if (e >= rows * ctot) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int k = 0;
-  for (; k + 3 < nblk; k += 4) {
-    s0 += slab[(int64_t)k * rows * ctot + e];
-    s1 += slab[(int64_t)(k + 1) * rows * ctot + e];
-    s2 += slab[(int64_t)(k + 2) * rows * ctot + e];
-    s3 += slab[(int64_t)(k + 3) * rows * ctot + e];
+  __shared__ float part[16][17];
+  const int o = threadIdx.x & 15, sg = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + o;                          // e = row * ctot + c
+  const int64_t n = (int64_t)rows * ctot;
+  float s0 = 0.f, s1 = 0.f;
+  if (e < n) {
+    int k = sg;
+    for (; k + 16 < nblk; k += 32) {
+      s0 += slab[(int64_t)k * n + e];
+      s1 += slab[(int64_t)(k + 16) * n + e];
+    }
+    if (k < nblk) s0 += slab[(int64_t)k * n + e];
   }
-  for (; k < nblk; ++k) s0 += slab[(int64_t)k * rows * ctot + e];
-  const int row = e / ctot, c = e % ctot;
-  dw[c * rows + row] = (s0 + s1) + (s2 + s3);
+  part[sg][o] = s0 + s1;
+  __syncthreads();
+  if (threadIdx.x < 16 && e < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += part[g][o];
+    const int row = e / ctot, c = e % ctot;
+    dw[c * rows + row] = t;
+  }
 }
 
-inline int edge_blocks(int64_t units) {       // 4 waves per workgroup, >= 2 units per wave when there is enough work
+inline int edge_blocks(int64_t units, int cap) {       // 4 waves per workgroup, >= 2 units per wave when there is enough work
   int64_t b = adn_cdiv(units, 8);
-  if (b > 1024) b = 1024;
+  if (b > cap) b = cap;
   if (b < 1) b = 1;
   return (int)b;
 }
+constexpr int kPixBlocks = 2048;    // l0_fwd: 8 workgroups per CU
+constexpr int kDgradBlocks = 768;   // d0_dgrad: 3 workgroups per CU (143 VGPRs), ~11 pixel groups per wave at B = 32
+constexpr int kWgradBlocks = 512;   // thin_wgrad: 2 per CU (64 KiB of LDS each), >= 8 K-steps per wave at B = 32
 
 }  // namespace
 
@@ -413,8 +460,10 @@ extern "C" int adn_l0_forward(const float* x, const float* w, int32_t B, int32_t
   ADN_CHECK_ARG(cin == 2 && cout == 64, "adn_l0_forward: built for 2 -> 64 channels (got %d -> %d)", cin, cout);
   ADN_CHECK_ARG(B > 0 && Hs > 0 && Ws > 0 && Ws % 16 == 0, "adn_l0_forward: bad shape B=%d Hs=%d Ws=%d (Ws %% 16)", B, Hs,
                 Ws);
-  const int64_t groups = (int64_t)B * Hs * (Ws / 16);
-  hipLaunchKernelGGL(l0_fwd_kernel, dim3(edge_blocks(groups)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, w,
+  ADN_CHECK_ARG((int64_t)B * Hs * Ws * 4 * 64 < (1ll << 40) && (int64_t)B * Hs * Ws * 4 < (1ll << 31),
+                "adn_l0_forward: tensor too large");
+  const int64_t units = (int64_t)B * Hs * (Ws / 16) / ((Ws / 16) % 4 == 0 ? 4 : 1);
+  hipLaunchKernelGGL(l0_fwd_kernel, dim3(edge_blocks(units * 2, kPixBlocks)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, w,
                      B, Hs, Ws, slope, reinterpret_cast<uint16_t*>(out_leaky), reinterpret_cast<uint16_t*>(out_relu));
   ADN_CHECK_LAUNCH();
   return ADN_OK;
@@ -422,7 +471,7 @@ extern "C" int adn_l0_forward(const float* x, const float* w, int32_t B, int32_t
 
 extern "C" int64_t adn_d0_dgrad_num_partials(int32_t B, int32_t Hs, int32_t Ws) {
   if (B <= 0 || Hs <= 0 || Ws <= 0 || Ws % 16) return -1;
-  return edge_blocks((int64_t)B * Hs * (Ws / 16));
+  return edge_blocks((int64_t)B * Hs * (Ws / 16), kDgradBlocks);
 }
 
 extern "C" int adn_d0_dgrad(const float* dz, const float* w, int32_t B, int32_t Hs, int32_t Ws, const AdnEpiSeg* seg0,
@@ -431,6 +480,7 @@ extern "C" int adn_d0_dgrad(const float* dz, const float* w, int32_t B, int32_t 
   ADN_CHECK_ARG(B > 0 && Hs > 0 && Ws > 0 && Ws % 16 == 0, "adn_d0_dgrad: bad shape B=%d Hs=%d Ws=%d (Ws %% 16)", B, Hs, Ws);
   ADN_CHECK_ARG(seg0->channels == 64 && seg1->channels == 64, "adn_d0_dgrad: built for 64 + 64 input channels (got %d + %d)",
                 seg0->channels, seg1->channels);
+  ADN_CHECK_ARG((int64_t)B * Hs * Ws * 4 < (1ll << 31), "adn_d0_dgrad: tensor too large");
   D0Params p;
   p.dz = dz;
   p.w = w;
@@ -446,7 +496,7 @@ extern "C" int adn_d0_dgrad(const float* dz, const float* w, int32_t B, int32_t 
     ADN_CHECK_ARG(!p.seg[s].accumulate, "adn_d0_dgrad: accumulate is not supported");
   }
   ADN_CHECK_ARG(!p.seg[0].partials, "adn_d0_dgrad: statistics are produced for segment 1 only");
-  hipLaunchKernelGGL(d0_dgrad_kernel, dim3(edge_blocks((int64_t)B * Hs * (Ws / 16))), dim3(256), 0,
+  hipLaunchKernelGGL(d0_dgrad_kernel, dim3(edge_blocks((int64_t)B * Hs * (Ws / 16), kDgradBlocks)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), p);
   ADN_CHECK_LAUNCH();
   return ADN_OK;
@@ -454,7 +504,7 @@ extern "C" int adn_d0_dgrad(const float* dz, const float* w, int32_t B, int32_t 
 
 extern "C" int64_t adn_thin_wgrad_workspace_bytes(int32_t B, int32_t Hs, int32_t Ws, int32_t ct, int32_t c0, int32_t c1) {
   if (B <= 0 || Hs <= 0 || Ws <= 0 || Ws % 32 || (ct != 1 && ct != 2)) return -1;
-  return (int64_t)edge_blocks((int64_t)B * Hs * (Ws / 32)) * 16 * ct * (c0 + c1) * 4;
+  return (int64_t)edge_blocks((int64_t)B * Hs * (Ws / 32), kWgradBlocks) * 16 * ct * (c0 + c1) * 4;
 }
 
 extern "C" int adn_thin_wgrad(const float* thin, int32_t ct, const void* plain0, int32_t c0, const void* plain1,
@@ -465,6 +515,7 @@ extern "C" int adn_thin_wgrad(const float* thin, int32_t ct, const void* plain0,
                 Ws);
   ADN_CHECK_ARG((ct == 1 && c0 == 64 && c1 == 64) || (ct == 2 && c0 == 64 && c1 == 0),
                 "adn_thin_wgrad: built for (ct 1, 64 + 64 channels) and (ct 2, 64 channels), got ct %d, %d + %d", ct, c0, c1);
+  ADN_CHECK_ARG((int64_t)B * Hs * Ws * 4 < (1ll << 31), "adn_thin_wgrad: tensor too large");
   const int64_t need = adn_thin_wgrad_workspace_bytes(B, Hs, Ws, ct, c0, c1);
   ADN_CHECK_ARG(workspace_bytes >= need, "adn_thin_wgrad: workspace too small (%lld < %lld)", (long long)workspace_bytes,
                 (long long)need);
@@ -477,7 +528,7 @@ extern "C" int adn_thin_wgrad(const float* thin, int32_t ct, const void* plain0,
   p.Hs = Hs;
   p.Ws = Ws;
   p.slab = reinterpret_cast<float*>(workspace);
-  const int nblk = edge_blocks((int64_t)B * Hs * (Ws / 32));
+  const int nblk = edge_blocks((int64_t)B * Hs * (Ws / 32), kWgradBlocks);
   const int rows = 16 * ct, ctot = c0 + c1;
   // LDS: 4 waves x 2 staging buffers x 32 pixels x (c0 + c1) bf16, reused as the [4][rows][ctot] f32 reduction tile
   const int stage = 4 * 2 * 32 * ctot * 2, redb = 4 * rows * ctot * 4;
@@ -490,7 +541,7 @@ extern "C" int adn_thin_wgrad(const float* thin, int32_t ct, const void* plain0,
     hipLaunchKernelGGL((thin_wgrad_kernel<2, 4, 0>), dim3(nblk), dim3(256), lds, st, p);
   }
   ADN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(thin_wgrad_sum_kernel, dim3((unsigned)adn_cdiv(rows * ctot, 256)), dim3(256), 0, st, p.slab, nblk,
+  hipLaunchKernelGGL(thin_wgrad_sum_kernel, dim3((unsigned)adn_cdiv(rows * ctot, 16)), dim3(256), 0, st, p.slab, nblk,
                      rows, ctot, dw);
   ADN_CHECK_LAUNCH();
   return ADN_OK;

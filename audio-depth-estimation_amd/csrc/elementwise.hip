@@ -91,6 +91,38 @@ __global__ __launch_bounds__(256) void pack_t2_multi_kernel(const S* flat_master
   const int pw = (kw & 1) ? 0 : 1, tx = (kw == 3 || kw == 2) ? 1 : 0;
   const int phase = ph * 2 + pw, t = ty * 2 + tx;
   const int x0 = (txy / tiles_y) * 64, y0 = (txy % tiles_y) * 64;
+  if ((X & 7) == 0 && (Y & 7) == 0) {
+    // vector form: 8 consecutive y per load (16 / 32 bytes), 8 consecutive x per store; a 64 x 64 tile = 512 chunks each way
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int item = threadIdx.x + 256 * it;
+      const int xx = item >> 3, c = item & 7;
+      const int x = x0 + xx, y = y0 + 8 * c;
+      float f[8];
+      if (x < X && y < Y) {
+        load8<S>(master, ((int64_t)x * 16 + tap) * Y + y, f);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) tile[xx][8 * c + e] = f[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int item = threadIdx.x + 256 * it;
+      const int yy = item >> 3, c = item & 7;
+      const int y = y0 + yy, x = x0 + 8 * c;
+      if (x < X && y < Y) {
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = tile[8 * c + e][yy];
+        store8<T>(t2, (((int64_t)phase * Y + y) * 4 + t) * X + x, f);
+      }
+    }
+    return;
+  }
   const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -239,9 +271,15 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* z, int64_t pixels,
   const int64_t n = pixels * C;
   if ((C & 7) == 0) {
     const int64_t groups = n >> 3;
+    // channel group of this thread, advanced incrementally (no 64-bit modulo per iteration)
+    const unsigned cpg = (unsigned)C >> 3;
+    const unsigned step = (unsigned)(((int64_t)gridDim.x * 256) % cpg);
+    unsigned cgp = (unsigned)(((int64_t)blockIdx.x * 256 + threadIdx.x) % cpg);
     for (int64_t gidx = (int64_t)blockIdx.x * 256 + threadIdx.x; gidx < groups; gidx += (int64_t)gridDim.x * 256) {
       const int64_t e = gidx << 3;
-      const int c = (int)(e % C);
+      const int c = (int)(cgp << 3);
+      cgp += step;
+      if (cgp >= cpg) cgp -= cpg;
       float v[8], o[8];
       load8<T>(z, e, v);
 #pragma unroll
@@ -287,9 +325,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(T* g, const T* z, int
   const int64_t n = pixels * C;
   if ((C & 7) == 0) {
     const int64_t groups = n >> 3;
+    const unsigned cpg = (unsigned)C >> 3;
+    const unsigned step = (unsigned)(((int64_t)gridDim.x * 256) % cpg);
+    unsigned cgp = (unsigned)(((int64_t)blockIdx.x * 256 + threadIdx.x) % cpg);
     for (int64_t gidx = (int64_t)blockIdx.x * 256 + threadIdx.x; gidx < groups; gidx += (int64_t)gridDim.x * 256) {
       const int64_t e = gidx << 3;
-      const int c = (int)(e % C);
+      const int c = (int)(cgp << 3);
+      cgp += step;
+      if (cgp >= cpg) cgp -= cpg;
       float gv[8], zv[8];
       load8<T>(g, e, gv);
       load8<T>(z, e, zv);
@@ -306,6 +349,155 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(T* g, const T* z, int
       const float xh = (ElemTraits<T>::load(z + e) - mean[c]) * istd[c];
       ElemTraits<T>::store(g + e, scale[c] * (ElemTraits<T>::load(g + e) - coef[c] - xh * coef[C + c]));
     }
+  }
+}
+
+
+// ---- small tensors (the innermost U-Net levels): finalize + apply in ONE launch -------------------------------------
+// A workgroup owns 32 channels.  Phase 1: it sums the P partial rows of its channels (thread = channel x 8 row
+// groups, 128-byte coalesced rows, f64) -- every row-slice workgroup of the same channels repeats this (the partials are
+// L2 resident) instead of waiting for a separate finalize launch; phase 2: it applies the affine map to its rows
+// (thread = 16-byte chunk x 64 rows per pass).  Replaces bn_*_finalize + bn_act / bn_bwd_apply (2 launches of 6-9 us
+// each at these sizes, launch-latency bound) by one.
+__device__ __forceinline__ void bn_block_sums(const float* partials, int64_t P, int C, int c0, double (*sh)[32][32],
+                                              double& s1, double& s2) {
+  // thread = 4 channels (one 16-byte load per partial row and statistic) x 32 row groups, 4 rows in flight per thread
+  const int cq = threadIdx.x & 7, rg = threadIdx.x >> 3;
+  double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
+  const float* base = partials + c0 + cq * 4;
+#pragma unroll 4
+  for (int64_t r = rg; r < P; r += 32) {
+    const f32x4_t x = *reinterpret_cast<const f32x4_t*>(base + (r * 2 + 0) * C);
+    const f32x4_t y = *reinterpret_cast<const f32x4_t*>(base + (r * 2 + 1) * C);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      a[k] += (double)x[k];
+      b[k] += (double)y[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    sh[0][rg][cq * 4 + k] = a[k];
+    sh[1][rg][cq * 4 + k] = b[k];
+  }
+  __syncthreads();
+  s1 = 0.0;
+  s2 = 0.0;
+  if (threadIdx.x < 32) {
+#pragma unroll 8
+    for (int g = 0; g < 32; ++g) {
+      s1 += sh[0][g][threadIdx.x];
+      s2 += sh[1][g][threadIdx.x];
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_fwd_fused_kernel(const float* partials, int64_t P, int C, double count,
+                                                           const float* gamma, const float* beta, float eps,
+                                                           float momentum, float* rmean, float* rvar, int64_t* nbt,
+                                                           float* mean, float* istd, float* scale, float* shift,
+                                                           const T* z, int64_t pixels, float slope, T* out_leaky,
+                                                           T* out_relu) {
+  __shared__ double sh[2][32][32];
+  __shared__ float aff[2][32];
+  const int c0 = blockIdx.x * 32;
+  double s1, s2;
+  bn_block_sums(partials, P, C, c0, sh, s1, s2);
+  if (threadIdx.x < 32) {
+    const int c = c0 + threadIdx.x;
+    const double mu = s1 / count;
+    double var = s2 / count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const double is = 1.0 / sqrt(var + (double)eps);
+    const double g = gamma ? (double)gamma[c] : 1.0, b = beta ? (double)beta[c] : 0.0;
+    const float sc = (float)(g * is), shf = (float)(b - mu * g * is);
+    aff[0][threadIdx.x] = sc;
+    aff[1][threadIdx.x] = shf;
+    if (blockIdx.y == 0) {                  // one row-slice workgroup publishes the statistics
+      mean[c] = (float)mu;
+      istd[c] = (float)is;
+      scale[c] = sc;
+      shift[c] = shf;
+      if (rmean) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        rmean[c] = (float)((1.0 - momentum) * (double)rmean[c] + momentum * mu);
+        rvar[c] = (float)((1.0 - momentum) * (double)rvar[c] + momentum * unbiased);
+      }
+      if (nbt && c == 0) nbt[0] += 1;
+    }
+  }
+  __syncthreads();
+  const int chunk = threadIdx.x & 3;
+  float sc[8], shf[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    sc[k] = aff[0][chunk * 8 + k];
+    shf[k] = aff[1][chunk * 8 + k];
+  }
+  for (int64_t r = (int64_t)blockIdx.y * 64 + (threadIdx.x >> 2); r < pixels; r += (int64_t)gridDim.y * 64) {
+    const int64_t e = r * C + c0 + chunk * 8;
+    float v[8], o[8];
+    load8<T>(z, e, v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = v[k] * sc[k] + shf[k];
+    if (out_leaky) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = v[k] > 0.f ? v[k] : v[k] * slope;
+      store8<T>(out_leaky, e, o);
+    }
+    if (out_relu) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = fmaxf(v[k], 0.f);
+      store8<T>(out_relu, e, o);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_fused_kernel(const float* partials, int64_t P, int C, double count,
+                                                           float* dgamma, float* dbeta, T* g, const T* z,
+                                                           int64_t pixels, const float* scale, const float* mean,
+                                                           const float* istd) {
+  __shared__ double sh[2][32][32];
+  __shared__ float cf[5][32];            // scale, mean, istd, sum g / n, sum g xhat / n
+  const int c0 = blockIdx.x * 32;
+  double s1, s2;
+  bn_block_sums(partials, P, C, c0, sh, s1, s2);
+  if (threadIdx.x < 32) {
+    const int c = c0 + threadIdx.x;
+    if (blockIdx.y == 0) {
+      if (dbeta) dbeta[c] = (float)s1;
+      if (dgamma) dgamma[c] = (float)s2;
+    }
+    cf[0][threadIdx.x] = scale[c];
+    cf[1][threadIdx.x] = mean[c];
+    cf[2][threadIdx.x] = istd[c];
+    cf[3][threadIdx.x] = (float)(s1 / count);
+    cf[4][threadIdx.x] = (float)(s2 / count);
+  }
+  __syncthreads();
+  const int chunk = threadIdx.x & 3;
+  float k0[8], k1[8], k2[8], k3[8], k4[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    k0[k] = cf[0][chunk * 8 + k];
+    k1[k] = cf[1][chunk * 8 + k];
+    k2[k] = cf[2][chunk * 8 + k];
+    k3[k] = cf[3][chunk * 8 + k];
+    k4[k] = cf[4][chunk * 8 + k];
+  }
+  for (int64_t r = (int64_t)blockIdx.y * 64 + (threadIdx.x >> 2); r < pixels; r += (int64_t)gridDim.y * 64) {
+    const int64_t e = r * C + c0 + chunk * 8;
+    float gv[8], zv[8];
+    load8<T>(g, e, gv);
+    load8<T>(z, e, zv);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float xh = (zv[k] - k1[k]) * k2[k];
+      gv[k] = k0[k] * (gv[k] - k3[k] - xh * k4[k]);
+    }
+    store8<T>(g, e, gv);
   }
 }
 
@@ -454,6 +646,63 @@ extern "C" int adn_bn_bwd_apply(void* g, const void* z, int64_t pixels, int32_t 
     hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(blocks_for(work)), dim3(256), 0, st,
                        reinterpret_cast<float*>(g), reinterpret_cast<const float*>(z), pixels, C, scale, mean, istd,
                        coef);
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}
+
+
+// row slices per channel block of the fused small-tensor kernels: enough workgroups to cover the chip's CUs a few waves deep
+static inline unsigned bn_fused_slices(int64_t pixels, int32_t C) {
+  int64_t sl = adn_cdiv(pixels, 256);
+  const int64_t cap = adn_cdiv(512, C / 32);
+  if (sl > cap) sl = cap;
+  if (sl < 1) sl = 1;
+  return (unsigned)sl;
+}
+
+extern "C" int adn_bn_fwd_fused(const float* partials, int64_t P, int32_t C, int64_t count, const float* gamma,
+                                const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                int64_t* num_batches_tracked, float* mean, float* istd, float* scale, float* shift,
+                                const void* z, int64_t pixels, int32_t dtype, float slope, void* out_leaky, void* out_relu,
+                                void* stream) {
+  ADN_CHECK_ARG(partials && P > 0 && C > 0 && count > 0 && mean && istd && scale && shift && z && pixels > 0 &&
+                    (out_leaky || out_relu),
+                "adn_bn_fwd_fused: bad arguments");
+  ADN_CHECK_ARG(C % 32 == 0, "adn_bn_fwd_fused: C must be a multiple of 32 (got %d)", C);
+  ADN_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "adn_bn_fwd_fused: running stats mismatch");
+  ADN_CHECK_ARG(dtype == ADN_F32 || dtype == ADN_BF16, "adn_bn_fwd_fused: bad dtype %d", dtype);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)(C / 32), bn_fused_slices(pixels, C));
+  if (dtype == ADN_BF16)
+    hipLaunchKernelGGL((bn_fwd_fused_kernel<uint16_t>), grid, dim3(256), 0, st, partials, P, C, (double)count, gamma, beta,
+                       eps, momentum, running_mean, running_var, num_batches_tracked, mean, istd, scale, shift,
+                       reinterpret_cast<const uint16_t*>(z), pixels, slope, reinterpret_cast<uint16_t*>(out_leaky),
+                       reinterpret_cast<uint16_t*>(out_relu));
+  else
+    hipLaunchKernelGGL((bn_fwd_fused_kernel<float>), grid, dim3(256), 0, st, partials, P, C, (double)count, gamma, beta,
+                       eps, momentum, running_mean, running_var, num_batches_tracked, mean, istd, scale, shift,
+                       reinterpret_cast<const float*>(z), pixels, slope, reinterpret_cast<float*>(out_leaky),
+                       reinterpret_cast<float*>(out_relu));
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}
+
+extern "C" int adn_bn_bwd_fused(const float* partials, int64_t P, int32_t C, int64_t count, float* dgamma, float* dbeta,
+                                void* g, const void* z, int64_t pixels, int32_t dtype, const float* scale,
+                                const float* mean, const float* istd, void* stream) {
+  ADN_CHECK_ARG(partials && P > 0 && C > 0 && count > 0 && g && z && pixels > 0 && scale && mean && istd,
+                "adn_bn_bwd_fused: bad arguments");
+  ADN_CHECK_ARG(C % 32 == 0, "adn_bn_bwd_fused: C must be a multiple of 32 (got %d)", C);
+  ADN_CHECK_ARG(dtype == ADN_F32 || dtype == ADN_BF16, "adn_bn_bwd_fused: bad dtype %d", dtype);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)(C / 32), bn_fused_slices(pixels, C));
+  if (dtype == ADN_BF16)
+    hipLaunchKernelGGL((bn_bwd_fused_kernel<uint16_t>), grid, dim3(256), 0, st, partials, P, C, (double)count, dgamma,
+                       dbeta, reinterpret_cast<uint16_t*>(g), reinterpret_cast<const uint16_t*>(z), pixels, scale, mean,
+                       istd);
+  else
+    hipLaunchKernelGGL((bn_bwd_fused_kernel<float>), grid, dim3(256), 0, st, partials, P, C, (double)count, dgamma, dbeta,
+                       reinterpret_cast<float*>(g), reinterpret_cast<const float*>(z), pixels, scale, mean, istd);
   ADN_CHECK_LAUNCH();
   return ADN_OK;
 }

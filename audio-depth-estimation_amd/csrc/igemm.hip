@@ -198,6 +198,9 @@ __global__ __launch_bounds__(BM * NWN, 2) void igemm_mfma_kernel(KParams p) {
   int is_tap = WIDE ? s_begin / kpt : 0;
   int is_c0 = WIDE ? (s_begin - is_tap * kpt) * BK : 0;
 
+  // One K-step of LDS-DMA = APASS + BPASS wave-instructions, issued right behind the step's barrier.  (Measured and
+  // rejected in round 2: spreading the pieces between the MFMA rows of the step with sched_barrier fences -- L3 forward
+  // 55 -> 67 us, D4 forward 60 -> 80 us, the others within 3 %.)
   auto issue_step = [&](int s, int buf) {
     char* adst = smem + buf * STAGE_BYTES + wave * 1024;
     char* bdst = adst + BM * 128;
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(BM * NWN, 2) void igemm_mfma_kernel(KParams p) {
       if constexpr (GEOM == ADN_GEMM_S2) shift = (tap >> 2) * Wl + (tap & 3);
       else if constexpr (GEOM == ADN_GEMM_T2) shift = (adn_t2_dy(ph, tap >> 1) + 1) * Ws + (adn_t2_dy(pw, tap & 1) + 1);
       else shift = (tap / ks) * Ws + tap % ks;
-      const int soff = (shift * Cs + coff) * ESZ + lc * 0;
+      const int soff = (shift * Cs + coff) * ESZ;
       const unsigned lane_c = (unsigned)(lc * EPC * ESZ);
 #pragma unroll
       for (int j = 0; j < APASS; ++j) {
@@ -272,11 +275,9 @@ __global__ __launch_bounds__(BM * NWN, 2) void igemm_mfma_kernel(KParams p) {
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    {
-      int nb = cur + STAGES - 1;
-      if (nb >= STAGES) nb -= STAGES;
-      if (s + STAGES - 1 < s_end) issue_step(s + STAGES - 1, nb);
-    }
+    int nb = cur + STAGES - 1;
+    if (nb >= STAGES) nb -= STAGES;
+    if (s + STAGES - 1 < s_end) issue_step(s + STAGES - 1, nb);
     const char* Ab = smem + cur * STAGE_BYTES;
     const char* Bb = Ab + BM * 128;
 #pragma unroll
@@ -567,7 +568,9 @@ bool make_plan(const AdnIgemmDesc* d, Plan* pl) {
     ns = (int)(512 / tiles);          // stay within one resident wave of workgroups (256 CUs x 2)
     const int max_by_k = pl->ksteps / 2 > 0 ? pl->ksteps / 2 : 1;
     if (ns > max_by_k) ns = max_by_k;
-    if (ns > 64) ns = 64;
+    // more than 16 slabs cost more in slab traffic (ns x M x N x 8 bytes written + read back) than the extra
+    // workgroups return: L5 / L6 forward 23.6 / 20.8 -> 20.3 / 16.1 us, D6 dgrad 25.7 -> 19.4 us at a cap of 16
+    if (ns > 16) ns = 16;
     if (ns < 1) ns = 1;
   }
   if (tn.ns >= 1 && ns > tn.ns) ns = tn.ns;                  // tuning knob: cap on the split count

@@ -20,8 +20,11 @@ __device__ __forceinline__ double block_sum_d(double v, double* sh) {
   return t;
 }
 
+// mask_mode: low two bits = validity rule (0: gt != 0, 1: gt > 0, 2: every pixel); bit 2 (ADN_MASK_SQUARED = 4):
+// the second statistic is the sum of SQUARED errors instead of absolute errors (criterion 4 = masked MSE)
 __device__ __forceinline__ bool valid_px(float g, int mask_mode) {
-  return mask_mode == 0 ? (g != 0.0f) : (mask_mode == 1 ? (g > 0.0f) : true);
+  const int m = mask_mode & 3;
+  return m == 0 ? (g != 0.0f) : (m == 1 ? (g > 0.0f) : true);
 }
 
 __global__ __launch_bounds__(256) void loss_stats_partial_kernel(const float* pred, const float* gt, int64_t n,
@@ -35,7 +38,7 @@ __global__ __launch_bounds__(256) void loss_stats_partial_kernel(const float* pr
       const float p = pred[i] * scale, g = g0 * scale;
       const float d = logf(fmaxf(p, eps)) - logf(fmaxf(g, eps));
       cN += 1.0;
-      sA += (double)fabsf(p - g);
+      sA += (mask_mode & 4) ? (double)(p - g) * (double)(p - g) : (double)fabsf(p - g);
       sD += (double)d;
       sD2 += (double)d * (double)d;
     }
@@ -77,11 +80,24 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const float* pred, con
     const double var = stats[3] / N - (double)lam * mean_d * mean_d;
     silog = var > 0.0 ? sqrt(var) : 0.0;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0 && loss_out) {
+  if (criterion != 4 && blockIdx.x == 0 && threadIdx.x == 0 && loss_out) {
     // an empty mask gives mean-of-empty = NaN in the reference (train.py:656); keep that signal
     loss_out[0] = N > 0.0 ? (float)(w1 * l1 + w2 * silog) : __int_as_float(0x7fc00000);
   }
   if (!grad) return;
+  if (criterion == 4) {            // masked MSE (BaseResidualLoss use_l1 = False, utils_base_residual_loss.py:60-65)
+    w1 = (double)l1w;
+    w2 = 0.0;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && loss_out)
+      loss_out[0] = N > 0.0 ? (float)(w1 * stats[1] / N) : __int_as_float(0x7fc00000);
+    if (!grad) return;
+    const float c = N > 0.0 ? (float)(2.0 * w1 * (double)scale / N) : 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+      const float g0 = gt[i];
+      grad[i] = valid_px(g0, mask_mode) ? c * (pred[i] * scale - g0 * scale) : 0.f;
+    }
+    return;
+  }
   const float c1 = N > 0.0 ? (float)(w1 * (double)scale / N) : 0.f;
   const float c2 = (N > 0.0 && silog > 0.0) ? (float)(w2 * (double)scale / (N * silog)) : 0.f;
   const float lm = (float)((double)lam * mean_d);
@@ -246,7 +262,7 @@ extern "C" int64_t adn_loss_workspace_bytes(int64_t n) { return (int64_t)red_blo
 extern "C" int adn_loss_stats(const float* pred, const float* gt, int64_t n, float scale, int32_t mask_mode,
                               float eps, double* stats, void* workspace, int64_t workspace_bytes, void* stream) {
   ADN_CHECK_ARG(pred && gt && n > 0 && stats && workspace, "adn_loss_stats: bad arguments");
-  ADN_CHECK_ARG(mask_mode >= 0 && mask_mode <= 2, "adn_loss_stats: bad mask_mode %d", mask_mode);
+  ADN_CHECK_ARG(mask_mode >= 0 && (mask_mode & 3) <= 2 && mask_mode < 8, "adn_loss_stats: bad mask_mode %d", mask_mode);
   const unsigned nb = red_blocks(n);
   ADN_CHECK_ARG(workspace_bytes >= (int64_t)nb * 32, "adn_loss_stats: workspace too small");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -262,8 +278,10 @@ extern "C" int adn_loss_finish(const float* pred, const float* gt, int64_t n, fl
                                float eps, const double* stats, int32_t criterion, float l1_weight, float silog_weight,
                                float silog_lambda, float* loss_out, float* grad, void* stream) {
   ADN_CHECK_ARG(pred && gt && n > 0 && stats, "adn_loss_finish: bad arguments");
-  ADN_CHECK_ARG(criterion >= 0 && criterion <= 2, "adn_loss_finish: bad criterion %d", criterion);
-  ADN_CHECK_ARG(mask_mode >= 0 && mask_mode <= 2, "adn_loss_finish: bad mask_mode %d", mask_mode);
+  ADN_CHECK_ARG((criterion >= 0 && criterion <= 2) || criterion == 4, "adn_loss_finish: bad criterion %d", criterion);
+  ADN_CHECK_ARG((criterion == 4) == ((mask_mode & 4) != 0),
+                "adn_loss_finish: criterion 4 (MSE) needs statistics taken with mask_mode | 4, and only it does");
+  ADN_CHECK_ARG(mask_mode >= 0 && (mask_mode & 3) <= 2 && mask_mode < 8, "adn_loss_finish: bad mask_mode %d", mask_mode);
   ADN_CHECK_ARG(loss_out || grad, "adn_loss_finish: nothing to compute");
   int64_t nb = grad ? adn_cdiv(n, 256) : 1;
   if (nb > 4096) nb = 4096;

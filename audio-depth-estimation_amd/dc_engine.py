@@ -363,11 +363,14 @@ class Head1x1(Op):
     align_corners=False), rgb_depth_model.py:200-209, binaural_attention_model.py:326-337): the head then runs
     unclamped (act 0 -> identity), adn_resize_bilinear and adn_clamp_range follow; backward in reverse."""
 
-    def __init__(self, src, conv, act, max_depth, out_size=None):
+    def __init__(self, src, conv, act, max_depth, out_size=None, clamp_after_resize=True):
         self.src, self.conv, self.act, self.max_depth = src, conv, act, float(max_depth)
         assert conv.kernel_size == (1, 1) and conv.out_channels == 1
         self.out_size = out_size                  # the caller applies the reference's rule (width != output_size)
-        if self.out_size is not None:
+        # clamp_after_resize False: the Base+Residual heads resize the ACTIVATED map and clamp only base + residual
+        # (base_residual_model.py:185-211): head with its activation -> adn_resize_bilinear, nothing else
+        self.clamp_after_resize = clamp_after_resize
+        if self.out_size is not None and clamp_after_resize:
             self.act = {0: 3, 1: 1}[act]          # sigmoid * max_depth already lies inside the clamp range
         src.consumers.append(self)
 
@@ -404,6 +407,10 @@ class Head1x1(Op):
             return
         s = self.src
         K.head1x1_fwd(s.data, self._weight(eng), self.conv.bias, self.act, self.max_depth, self.zpre, self.pre)
+        if not self.clamp_after_resize:
+            K.resize_bilinear(self.pre.view(eng.B, s.H, s.W), self.out_size, False, self.result.view(eng.B, self.out_size,
+                                                                                                     self.out_size))
+            return
         K.resize_bilinear(self.pre.view(eng.B, s.H, s.W), self.out_size, False, self.resized)
         K.clamp_range(self.resized, self.max_depth, self.result)
 
@@ -411,8 +418,12 @@ class Head1x1(Op):
         s = self.src
         assert not s.written
         if self.out_size is not None:
-            K.clamp_range(self.resized, self.max_depth, self.gres, g=gout.contiguous())
-            K.resize_bilinear_bwd(self.gres, s.H, s.W, self.gpre.view(eng.B, s.H, s.W))
+            if self.clamp_after_resize:
+                K.clamp_range(self.resized, self.max_depth, self.gres, g=gout.contiguous())
+                K.resize_bilinear_bwd(self.gres, s.H, s.W, self.gpre.view(eng.B, s.H, s.W))
+            else:
+                K.resize_bilinear_bwd(gout.contiguous().view(eng.B, self.out_size, self.out_size), s.H, s.W,
+                                      self.gpre.view(eng.B, s.H, s.W))
             gout = self.gpre
         padded = self.c_real != s.C
         w = self.w_p if padded else eng._flat_slice(eng.flat_p, self.conv.weight)

@@ -228,8 +228,7 @@ class UNetEngine(FlatParamEngine):
             elif training:
                 K.igemm(T, GEMM_S2, B, hs, wsz, src, None, lv['down_s2'], C, EPI_Z_STATS,
                         [K.Seg(C, out0=lv['zd'], partials=lv['part_d'])], ws)
-                self._bn_finalize(lv, 'd', bn, B * hs * wsz, lv['P_d'])
-                K.bn_act(lv['zd'], B * hs * wsz, C, lv['scale_d'], lv['shift_d'], LEAKY, lv['ad'], lv['rd'])
+                self._bn_forward(lv, 'd', bn, B * hs * wsz, lv['P_d'], lv['zd'], LEAKY, lv['ad'], lv['rd'])
             else:
                 K.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var, BN_EPS, lv['scale_d'],
                                  lv['shift_d'])
@@ -255,8 +254,7 @@ class UNetEngine(FlatParamEngine):
             elif training:
                 K.igemm(T, GEMM_T2, B, hs, wsz, in0, in1, lv['up_t2'], C, EPI_Z_STATS,
                         [K.Seg(C, out0=lv['zu'], partials=lv['part_u'])], ws)
-                self._bn_finalize(lv, 'u', bn, B * 4 * hs * wsz, lv['P_u'])
-                K.bn_act(lv['zu'], B * 4 * hs * wsz, C, lv['scale_u'], lv['shift_u'], 0.0, None, lv['ru'])
+                self._bn_forward(lv, 'u', bn, B * 4 * hs * wsz, lv['P_u'], lv['zu'], 0.0, None, lv['ru'])
             else:
                 K.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var, BN_EPS, lv['scale_u'],
                                  lv['shift_u'])
@@ -270,13 +268,35 @@ class UNetEngine(FlatParamEngine):
         K.nhwc_to_nchw(out, res)
         return res
 
-    def _bn_finalize(self, lv, tag, bn, count, P):
+    # tensors up to this many elements take the one-launch finalize + apply kernels (innermost levels: the two
+    # separate launches cost 6-9 us each there, launch-latency bound)
+    BN_FUSED_MAX = 1 << 20
+
+    def _bn_forward(self, lv, tag, bn, count, P, z, slope, out_leaky, out_relu):
+        """Train-mode BatchNorm + activation of a raw conv output: statistics finalize (+ running stats) and apply."""
         track = bn.track_running_stats and bn.running_mean is not None
-        K.bn_fwd_finalize(lv[f'part_{tag}'], P, lv[f'mean_{tag}'].numel(), count, bn.weight, bn.bias, BN_EPS,
-                          BN_MOMENTUM if bn.momentum is None else bn.momentum,
-                          bn.running_mean if track else None, bn.running_var if track else None,
-                          bn.num_batches_tracked if track else None,
-                          lv[f'mean_{tag}'], lv[f'istd_{tag}'], lv[f'scale_{tag}'], lv[f'shift_{tag}'])
+        C = lv[f'mean_{tag}'].numel()
+        args = (lv[f'part_{tag}'], P, C, count, bn.weight, bn.bias, BN_EPS,
+                BN_MOMENTUM if bn.momentum is None else bn.momentum,
+                bn.running_mean if track else None, bn.running_var if track else None,
+                bn.num_batches_tracked if track else None,
+                lv[f'mean_{tag}'], lv[f'istd_{tag}'], lv[f'scale_{tag}'], lv[f'shift_{tag}'])
+        if count * C <= self.BN_FUSED_MAX and C % 32 == 0:
+            K.bn_fwd_fused(*args, z, count, slope, out_leaky, out_relu)
+        else:
+            K.bn_fwd_finalize(*args)
+            K.bn_act(z, count, C, lv[f'scale_{tag}'], lv[f'shift_{tag}'], slope, out_leaky, out_relu)
+
+    def _bn_backward(self, lv, tag, bn, count, P, g, z):
+        """BatchNorm backward of the tensor BN'd at (level, tag): dgamma / dbeta + dz in place of g."""
+        C = lv[f'mean_{tag}'].numel()
+        dg, db = self._flat_slice(self.flat_g, bn.weight), self._flat_slice(self.flat_g, bn.bias)
+        if count * C <= self.BN_FUSED_MAX and C % 32 == 0:
+            K.bn_bwd_fused(lv[f'bpart_{tag}'], P, C, count, dg, db, g, z, count, lv[f'scale_{tag}'], lv[f'mean_{tag}'],
+                           lv[f'istd_{tag}'])
+        else:
+            K.bn_bwd_finalize(lv[f'bpart_{tag}'], P, C, count, dg, db, lv[f'coef_{tag}'])
+            K.bn_bwd_apply(g, z, count, C, lv[f'scale_{tag}'], lv[f'mean_{tag}'], lv[f'istd_{tag}'], lv[f'coef_{tag}'])
 
     # ------------------------------------------------------------------ backward
     def _ready(self, param):
@@ -302,13 +322,7 @@ class UNetEngine(FlatParamEngine):
             if i == 0:
                 dz = lv['dz0']
             else:
-                bn = lv['bn_u']
-                C = lv['cu_out']
-                K.bn_bwd_finalize(lv['bpart_u'], L[i - 1]['P_gu'], C, B * 4 * hs * wsz,
-                                  self._flat_slice(self.flat_g, bn.weight), self._flat_slice(self.flat_g, bn.bias),
-                                  lv['coef_u'])
-                K.bn_bwd_apply(lv['Gu'], lv['zu'], B * 4 * hs * wsz, C, lv['scale_u'], lv['mean_u'], lv['istd_u'],
-                               lv['coef_u'])
+                self._bn_backward(lv, 'u', lv['bn_u'], B * 4 * hs * wsz, L[i - 1]['P_gu'], lv['Gu'], lv['zu'])
                 dz = lv['Gu']
             in0 = lv['rd']
             in1 = L[i + 1]['ru'] if i < n - 1 else None
@@ -332,12 +346,7 @@ class UNetEngine(FlatParamEngine):
             lv = L[i]
             hs, wsz = lv['hs'], lv['ws']
             if lv['bn_d'] is not None:
-                bn, C = lv['bn_d'], lv['cd_out']
-                K.bn_bwd_finalize(lv['bpart_d'], L[i + 1]['P_gd'], C, B * hs * wsz,
-                                  self._flat_slice(self.flat_g, bn.weight), self._flat_slice(self.flat_g, bn.bias),
-                                  lv['coef_d'])
-                K.bn_bwd_apply(lv['Gd'], lv['zd'], B * hs * wsz, C, lv['scale_d'], lv['mean_d'], lv['istd_d'],
-                               lv['coef_d'])
+                self._bn_backward(lv, 'd', lv['bn_d'], B * hs * wsz, L[i + 1]['P_gd'], lv['Gd'], lv['zd'])
             src = self.x_nhwc if i == 0 else L[i - 1]['ad']
             if i == 0 and self.edge_path:
                 if self._x_in._version != self._x_ver:
@@ -492,19 +501,38 @@ class FusedTrainer:
         self._ready = True
 
     def state_dict(self):
-        """Optimizer state (flat Adam moments + step counters) for the checkpoint's 'optimizer' entry."""
-        if not self._ready:
-            return {'kind': self.opt_kind, 'lr': self.lr, 'step': 0}
-        return {'kind': self.opt_kind, 'lr': self.lr, 'betas': self.betas, 'eps': self.eps,
-                'weight_decay': self.weight_decay, 'step': int(self.state[0].item()),
-                'exp_avg': self.exp_avg.detach().cpu(), 'exp_avg_sq': self.exp_avg_sq.detach().cpu()}
+        """The checkpoint's 'optimizer' / 'optimizer_state_dict' entry in ``torch.optim`` format (optim_state.py): what
+        ``torch.optim.AdamW(model.parameters(), ...).state_dict()`` would hold after the same steps, so the reference's
+        ``optimizer.load_state_dict`` (train_binaural_attention.py:361) reads it and vice versa."""
+        from . import optim_state
+        eng = self.engine
+        if not eng._bound():
+            eng.bind_parameters()
+        step = int(self.state[0].item()) if self._ready else 0
+        return optim_state.export_state(eng.param_meta, eng._view, self.exp_avg if self._ready else None,
+                                        self.exp_avg_sq if self._ready else None, step, self.opt_kind, self.lr,
+                                        self.betas, self.eps, self.weight_decay)
 
     def load_state_dict(self, sd, device):
+        """Restore a ``torch.optim`` state dict (written by this class or by the reference's torch optimizer over the
+        same parameters); the flat layout of round 1 ('exp_avg' / 'exp_avg_sq' / 'step') is still read."""
+        from . import optim_state
         self._setup(device)
-        if 'exp_avg' in sd:
+        if optim_state.is_torch_format(sd):
+            step, group = optim_state.import_state(sd, self.engine.param_meta, self.engine._view, self.exp_avg,
+                                                   self.exp_avg_sq)
+            self._set_step(step)
+            self.lr = float(group.get('lr', self.lr))
+        elif 'exp_avg' in sd:
             self.exp_avg.copy_(sd['exp_avg'])
             self.exp_avg_sq.copy_(sd['exp_avg_sq'])
-            self.state[0] = float(sd['step'])
+            self._set_step(int(sd['step']))
+
+    def _set_step(self, step):
+        """state = [step, 1 - beta1^step, 1 - beta2^step, ...] (adn_optimizer_step advances all three)."""
+        self.state[0] = float(step)
+        self.state[1] = 1.0 - self.betas[0] ** step
+        self.state[2] = 1.0 - self.betas[1] ** step
 
     def step(self, audio, gt):
         self._calls += 1

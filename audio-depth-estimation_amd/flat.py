@@ -12,7 +12,7 @@ from __future__ import annotations
 import torch
 
 
-def _align(n, a=4):
+def _align(n, a=8):       # 8 elements: 32-byte f32 slices, 16-byte slices of the bf16 mirror
     return (n + a - 1) // a * a
 
 

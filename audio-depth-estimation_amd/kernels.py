@@ -222,6 +222,22 @@ def bn_fwd_finalize(partials, P, Cc, count, gamma, beta, eps, momentum, running_
               _stream())
 
 
+def bn_fwd_fused(partials, P, Cc, count, gamma, beta, eps, momentum, running_mean, running_var, nbt, mean, istd, scale,
+                 shift, z, pixels, slope, out_leaky, out_relu):
+    """bn_fwd_finalize + bn_act in one launch (small tensors, C % 32 == 0)."""
+    _dev(partials, mean, istd, scale, shift, z, out_leaky, out_relu)
+    _lib.call('adn_bn_fwd_fused', ptr(partials), P, Cc, count, ptr(gamma), ptr(beta), eps, momentum, ptr(running_mean),
+              ptr(running_var), ptr(nbt), ptr(mean), ptr(istd), ptr(scale), ptr(shift), ptr(z), pixels,
+              dtype_code(z.dtype), float(slope), ptr(out_leaky), ptr(out_relu), _stream())
+
+
+def bn_bwd_fused(partials, P, Cc, count, dgamma, dbeta, g, z, pixels, scale, mean, istd):
+    """bn_bwd_finalize + bn_bwd_apply (g in place) in one launch (small tensors, C % 32 == 0)."""
+    _dev(partials, g, z, scale, mean, istd)
+    _lib.call('adn_bn_bwd_fused', ptr(partials), P, Cc, count, ptr(dgamma), ptr(dbeta), ptr(g), ptr(z), pixels,
+              dtype_code(g.dtype), ptr(scale), ptr(mean), ptr(istd), _stream())
+
+
 def bn_eval_affine(gamma, beta, running_mean, running_var, eps, scale, shift):
     _dev(running_mean, scale)
     _lib.call('adn_bn_eval_affine', ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), eps,

@@ -53,6 +53,12 @@ def build_parser():
     g.add_argument('--audio_format', type=str, default=None, choices=['spectrogram', 'mel_spectrogram', 'waveform'])
     g.add_argument('--eval_img', action='store_true', default=False)
     g.add_argument('--max_depth', type=float, default=None)
+    # sequence hold-out / wandb flags of the reference (train.py:76-81, :113-126): accepted so that reference command
+    # lines run unchanged; the plumbing behind them (CSV filtering by sequence, W&B logging) is out of scope and a
+    # warning says so when they are set
+    g.add_argument('--sequence_holdout', action='store_true', default=False)
+    g.add_argument('--holdout_test_seq', type=str, default=None)
+    g.add_argument('--holdout_eval_seq', type=str, default=None)
     g = p.add_argument_group('Training Hyperparameters')
     g.add_argument('--batch_size', type=int, default=None)
     g.add_argument('--learning_rate', '--lr', type=float, default=None)
@@ -66,6 +72,10 @@ def build_parser():
     g = p.add_argument_group('Validation & Logging')
     g.add_argument('--validation', type=lambda x: (str(x).lower() == 'true'), default=None)
     g.add_argument('--validation_iter', type=int, default=None)
+    g.add_argument('--use_wandb', action='store_true', default=False)
+    g.add_argument('--wandb_project', type=str, default='batvision-depth-estimation')
+    g.add_argument('--wandb_entity', type=str, default='branden')
+    g.add_argument('--wandb_mode', type=str, default='online', choices=['online', 'offline', 'disabled'])
     g.add_argument('--save_best_model', action='store_true', default=True)
     g.add_argument('--best_metric', type=str, default='rmse', choices=['rmse', 'abs_rel', 'delta1', 'mae', 'loss'])
     g = p.add_argument_group('Experiment Management')
@@ -135,27 +145,44 @@ def make_loaders(cfg, args, rank, world):
     return tl, vl, fe, sampler
 
 
-def validate(model, loader, fe, cfg, device):
-    """Per-sample metrics of train.py:782-838 (clip pred to [eps, max_depth], gt >= 0), one kernel per batch."""
+def validate(model, loader, fe, cfg, device, loss_spec=None):
+    """Per-sample metrics of train.py:782-838 (clip pred to [eps, max_depth], gt >= 0), one kernel per batch, and the
+    validation loss of train.py:746-769: the training criterion over valid = gt > 0, in metres, mean of the per-batch
+    values (what --best_metric loss selects on, :875-881).  Returns (7 metrics, val_loss)."""
+    from . import kernels as K
     model.eval()
-    rows = []
+    rows, losses = [], []
     md = float(cfg.dataset.max_depth)
     eps = 1e-3 if cfg.dataset.depth_norm else 1e-6
+    scale = md if cfg.dataset.depth_norm else 1.0
+    stats = torch.zeros(4, dtype=torch.float64, device=device)
+    lws = torch.empty(4096 + 8, dtype=torch.float64, device=device)
     with torch.no_grad():
         for audio, gt in loader:
-            audio, gt = audio.to(device), gt.to(device)
+            audio, gt = audio.to(device), gt.to(device).contiguous().float()
             if fe is not None:
                 audio = fe(audio)
             pred = model(audio)
+            if loss_spec is not None:
+                crit, l1w, sw, lam = loss_spec
+                lv = torch.zeros(1, device=device)
+                K.loss_stats(pred, gt, scale, 1, 1e-6, stats, lws)                      # mask gt > 0 (:747)
+                K.loss_finish(pred, gt, scale, 1, 1e-6, stats, {'L1': 0, 'SIlog': 1, 'Combined': 2}[crit], l1w, sw, lam,
+                              lv, None)
+                losses.append(lv)
             if cfg.dataset.depth_norm:
                 pred, gt = pred * md, gt * md
             rows.append(compute_errors_batch(gt.clamp(min=0.0), pred.clamp(eps, md)))
     model.train()
-    return torch.cat(rows).mean(0).tolist()
+    val_loss = float(torch.cat(losses).mean()) if losses else float('nan')
+    return torch.cat(rows).mean(0).tolist(), val_loss
 
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    if args.use_wandb or args.sequence_holdout or args.holdout_test_seq or args.holdout_eval_seq:
+        print('Warning: --use_wandb / --sequence_holdout / --holdout_* are accepted for command-line compatibility but '
+              'the W&B logging and the sequence hold-out filtering of the reference are not part of this build')
     cfg = load_config(dataset_name=args.dataset, mode='train', experiment_name=args.experiment_name)
     if args.checkpoints is not None:
         cfg.mode.checkpoints = args.checkpoints
@@ -229,10 +256,11 @@ def main(argv=None):
         if losses and rank == 0:
             print(f'Epoch {epoch}: Train Loss: {torch.stack(losses).mean().item():.6f}, Time: {time.time() - t0:.1f}s')
         if cfg.mode.validation and epoch % cfg.mode.validation_iter == 0 and rank == 0:
-            abs_rel, rmse, d1, d2, d3, log10, mae = validate(model, val_loader, fe, cfg, device)
-            print(f'Val - RMSE: {rmse:.3f}, ABS_REL: {abs_rel:.3f}, Log10: {log10:.3f}, Delta1: {d1:.3f}, '
+            (abs_rel, rmse, d1, d2, d3, log10, mae), val_loss = validate(model, val_loader, fe, cfg, device,
+                                                                         (crit, l1w, sw, lam))
+            print(f'Val - Loss: {val_loss:.6f}, RMSE: {rmse:.3f}, ABS_REL: {abs_rel:.3f}, Log10: {log10:.3f}, Delta1: {d1:.3f}, '
                   f'Delta2: {d2:.3f}, Delta3: {d3:.3f}, MAE: {mae:.3f}')
-            cur = {'rmse': rmse, 'abs_rel': abs_rel, 'delta1': d1, 'mae': mae, 'loss': rmse}[args.best_metric]
+            cur = {'rmse': rmse, 'abs_rel': abs_rel, 'delta1': d1, 'mae': mae, 'loss': val_loss}[args.best_metric]
             if args.save_best_model and ((cur > best) if args.best_metric == 'delta1' else (cur < best)):
                 best = cur
                 os.makedirs(ckpt_dir, exist_ok=True)

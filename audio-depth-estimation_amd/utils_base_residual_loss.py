@@ -13,15 +13,19 @@ import torch.nn as nn
 from . import kernels as K
 
 
+def recon_criterion(use_l1, use_silog):
+    """(libadn criterion code, mask mode) of the reconstruction term over valid = gt > 0: Combined with one active weight
+    (= weighted SIlog or L1), or the masked MSE (criterion 4, squared-error statistics = mask mode | 4)."""
+    return (2, 1) if (use_silog or use_l1) else (4, 1 | 4)
+
+
 class BaseResidualLoss(nn.Module):
     """lambda_recon * recon(final, gt) + lambda_base * L1(base, lowpass(gt)) + lambda_sparse * mean|residual| over
-    valid = gt > 0 (reference :28-160); recon = SIlog (use_silog), L1 (use_l1) -- MSE is not implemented."""
+    valid = gt > 0 (reference :28-160); recon = SIlog (use_silog), else L1 (use_l1), else MSE (:60-65)."""
 
     def __init__(self, lambda_recon=1.0, lambda_base=1.2, lambda_sparse=0.05, lowpass_kernel=16, use_l1=True,
                  use_silog=False, silog_lambda=0.5):
         super().__init__()
-        if not use_silog and not use_l1:
-            raise NotImplementedError('the MSE reconstruction variant is not implemented on the libadn path')
         self.lambda_recon = lambda_recon
         self.lambda_base = lambda_base
         self.lambda_sparse = lambda_sparse
@@ -47,8 +51,9 @@ class BaseResidualLoss(nn.Module):
         lws = torch.empty(4096 + 8, **f64)
         recon, terms, scratch = torch.zeros(1, **f32), torch.zeros(4, **f32), torch.empty_like(gt)
         l1w, sw = (0.0, self.lambda_recon) if self.use_silog else (self.lambda_recon, 0.0)
-        K.loss_stats(final, gt, 1.0, 1, 1e-6, lstats, lws)
-        K.loss_finish(final, gt, 1.0, 1, 1e-6, lstats, 2, l1w, sw, self.silog_lambda, recon, scratch)
+        crit, mm = recon_criterion(self.use_l1, self.use_silog)
+        K.loss_stats(final, gt, 1.0, mm, 1e-6, lstats, lws)
+        K.loss_finish(final, gt, 1.0, mm, 1e-6, lstats, crit, l1w, sw, self.silog_lambda, recon, scratch)
         K.baseres_stats(base, resid, struct, gt, recon, self.lambda_recon, self.lambda_base, self.lambda_sparse, bstats,
                         terms, ws)
         t = terms.cpu().tolist()

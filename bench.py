@@ -91,22 +91,114 @@ def cpu_baseline(B, steps, warmup):
                       f'torch {torch.__version__} CPU, {cores} threads'}
 
 
+def build_trainer(dtype, device, reducer):
+    from audio_depth_estimation_amd.engine import FusedTrainer
+    from audio_depth_estimation_amd.models.unetbaseline_model import define_G
+    cfg = SimpleNamespace(dataset=SimpleNamespace(depth_norm=False, max_depth=30.0))
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(sys.stderr):      # define_G prints its init banner like the reference: keep stdout = the JSON line
+        model = define_G(cfg, 2, 1, 64, 'unet_256')
+    model.compute_dtype = dtype
+    model = model.to(device).train()
+    trainer = FusedTrainer(model.engine(), 'Combined', L1_W, SILOG_W, SILOG_LAMBDA, max_depth=30.0,
+                           optimizer='AdamW', lr=LR, clip_norm=1.0, ddp=reducer)
+    return model, trainer
+
+
+def gemm_event_pass(trainer, batches, prof_steps):
+    """The recorded launch plan replayed with a HIP event pair around every GEMM launch, on the stream the kernels run
+    on.  The host replays prebuilt calls, so the GPU queue stays full and the event intervals are kernel durations.
+    Returns {label: [algorithmic flops, seconds, launches]}."""
+    plan = trainer._plan
+    timed = [(i, e[3]) for i, e in enumerate(plan) if e[3].get('label') in ('igemm', 'wgrad')]
+    evs = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for i, _ in timed}
+    fam = {}
+    for it in range(prof_steps):
+        trainer._g_audio.copy_(batches[it % len(batches)][0])
+        trainer._g_gt.copy_(batches[it % len(batches)][1])
+        for i, (fn, a, name, meta) in enumerate(plan):
+            if i in evs:
+                evs[i][0].record()
+            if fn is None:
+                a()
+            else:
+                fn(*a)
+            if i in evs:
+                evs[i][1].record()
+        torch.cuda.synchronize()
+        for i, meta in timed:
+            acc = fam.setdefault(meta['label'], [0.0, 0.0, 0])
+            acc[0] += meta['flops']
+            acc[1] += evs[i][0].elapsed_time(evs[i][1]) * 1e-3
+            acc[2] += 1
+    return fam
+
+
+def per_step_times(trainer, batches, min_seconds, min_steps, max_steps=4000):
+    """Sustained run: steps until `min_seconds` have passed, one HIP event between consecutive steps; returns the
+    per-step durations (ms) and the wall time.  The events sit on the stream the step runs on."""
+    evs = [torch.cuda.Event(enable_timing=True)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    evs[0].record()
+    n = 0
+    while n < max_steps and (n < min_steps or time.perf_counter() - t0 < min_seconds):
+        trainer.step(*batches[n % len(batches)])
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        evs.append(e)
+        n += 1
+        if n % 64 == 0:
+            evs[-1].synchronize()          # keep the host at most 64 steps ahead: wall time then tracks the device
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    return [evs[k].elapsed_time(evs[k + 1]) for k in range(n)], wall
+
+
+def f32_exact_record(device, B, S, rank):
+    """The same train step on the exact-f32 MFMA path (the path that carries the 1e-4 tolerance of north_star)."""
+    model, trainer = build_trainer(torch.float32, device, None)
+    batches = [synth_batch(B, S, 1234 + 1000 * rank + i, device) for i in range(2)]
+    for i in range(3):
+        trainer.step(*batches[i % 2])
+    torch.cuda.synchronize()
+    trainer.enable_launch_plan(after_steps=0)
+    trainer.step(*batches[0])
+    torch.cuda.synchronize()
+    fam = gemm_event_pass(trainer, batches, 2)
+    trainer._plan, trainer._plan_after = None, None
+    trainer.enable_graph(after_steps=0)
+    trainer.step(*batches[0])
+    times, wall = per_step_times(trainer, batches, 1.0, 10, 200)
+    times.sort()
+    med = times[len(times) // 2]
+    flops = sum(v[0] for v in fam.values())
+    secs = sum(v[1] for v in fam.values())
+    del trainer, model
+    torch.cuda.empty_cache()
+    return {'dtype': 'f32', 'value': B / (med * 1e-3), 'unit': 'depth-maps/s', 'median_ms_per_step': med,
+            'steps': len(times), 'gemm_tflops': flops / secs / 1e12, 'peak': MFMA_PEAK_TF['f32'],
+            'frac': flops / secs / 1e12 / MFMA_PEAK_TF['f32'],
+            'note': 'exact-f32 MFMA path (v_mfma_f32_16x16x4_f32): predictions within 1e-4 relative L1 of the CPU reference'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=30)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=600)      # ~2 s of timed region at ~3.3 ms per step
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=32, help='per-GPU batch')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly (default for --gpus > 1)')
+    ap.add_argument('--no-f32', action='store_true', help='skip the exact-f32 sub-record (N=1 only)')
+    ap.add_argument('--sustain-seconds', type=float, default=2.0,
+                    help='length of the sustained per-step-event run behind the timed region (0 = skip)')
     ap.add_argument('--cpu-batch', type=int, default=8)
     ap.add_argument('--cpu-steps', type=int, default=25)     # B=8: about 12 s of host work (bounded sample)
     args = ap.parse_args()
 
     from audio_depth_estimation_amd import ddp as addp
-    from audio_depth_estimation_amd.engine import FusedTrainer
-    from audio_depth_estimation_amd.models.unetbaseline_model import define_G
 
     rank, world, local = addp.init_from_env('nccl')
     if world != args.gpus:
@@ -115,16 +207,9 @@ def main():
     device = torch.device('cuda', local % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(device)
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
-
-    cfg = SimpleNamespace(dataset=SimpleNamespace(depth_norm=False, max_depth=30.0))
-    torch.manual_seed(0)
-    with contextlib.redirect_stdout(sys.stderr):      # define_G prints its init banner like the reference: keep stdout = the JSON line
-        model = define_G(cfg, 2, 1, 64, 'unet_256')
-    model.compute_dtype = dtype
-    model = model.to(device).train()
     reducer = addp.GradientAllReducer() if world > 1 else None
-    trainer = FusedTrainer(model.engine(), 'Combined', L1_W, SILOG_W, SILOG_LAMBDA, max_depth=30.0,
-                           optimizer='AdamW', lr=LR, clip_norm=1.0, ddp=reducer)
+    backend = dist.get_backend() if world > 1 else None
+    model, trainer = build_trainer(dtype, device, reducer)
     B, S = args.batch, 256
     batches = [synth_batch(B, S, 1234 + 1000 * rank + i, device) for i in range(4)]
     if reducer is not None:
@@ -145,38 +230,15 @@ def main():
     trainer.enable_launch_plan(after_steps=0)
     trainer.step(*batches[0])
     barrier()
-    # Kernel-level pass: the same plan with a HIP event pair around every GEMM launch, recorded on the
-    # stream the kernels run on.  The host replays prebuilt calls, so the GPU queue stays full and the event
-    # intervals are kernel durations (an eager Python loop was host-bound once the kernels got fast).
-    plan = trainer._plan
-    timed = [(i, e[3]) for i, e in enumerate(plan) if e[3].get('label') in ('igemm', 'wgrad')]
-    evs = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for i, _ in timed}
-    prof_steps = min(args.steps, 5)
-    fam = {}
-    for it in range(prof_steps):
-        trainer._g_audio.copy_(batches[it % len(batches)][0])
-        trainer._g_gt.copy_(batches[it % len(batches)][1])
-        for i, (fn, a, name, meta) in enumerate(plan):
-            if i in evs:
-                evs[i][0].record()
-            if fn is None:
-                a()
-            else:
-                fn(*a)
-            if i in evs:
-                evs[i][1].record()
-        torch.cuda.synchronize()
-        for i, meta in timed:
-            acc = fam.setdefault(meta['label'], [0.0, 0.0, 0])
-            acc[0] += meta['flops']
-            acc[1] += evs[i][0].elapsed_time(evs[i][1]) * 1e-3
-            acc[2] += 1
+    prof_steps = max(1, min(args.steps, 5))
+    fam = gemm_event_pass(trainer, batches, prof_steps)
     barrier()
     if use_graph:
         trainer._plan, trainer._plan_after = None, None
         trainer.enable_graph(after_steps=0)          # N=1: the whole step is one hipGraph
         trainer.step(*batches[0])                    # capture + first replay (untimed)
         barrier()
+    # ---- the timed region of the contract: exactly K steps between two barrier + synchronize pairs
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss, _ = trainer.step(*batches[i % len(batches)])
@@ -187,6 +249,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     final_loss = float(loss.item())
+    # ---- sustained run behind it: >= 2 s of back-to-back steps, one event per step, median reported
+    sustained = None
+    if args.sustain_seconds > 0:
+        times, wall = per_step_times(trainer, batches, args.sustain_seconds, 50)
+        barrier()
+        st = sorted(times)
+        med = st[len(st) // 2]
+        sustained = {'steps': len(times), 'seconds': wall, 'value': world * B * len(times) / wall,
+                     'median_ms_per_step': med, 'p10_ms': st[len(st) // 10], 'p90_ms': st[(9 * len(st)) // 10],
+                     'value_at_median': world * B / (med * 1e-3)}
 
     if rank == 0:
         dom = max(fam, key=lambda k: fam[k][1])
@@ -194,16 +266,23 @@ def main():
         achieved = flops / secs / 1e12
         peak = MFMA_PEAK_TF[args.dtype]
         gemm_secs = sum(v[1] for v in fam.values())
-        # HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE in separate runs, read side doubled per MI355X_MICROARCH.md); null when not collected
-        traffic = None
-        try:
-            pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic_gemm.json')))
-            rows = [v for k, v in pm.items() if k.startswith(dom)]
-            if rows and args.dtype == 'bf16' and B == 32:
-                traffic = sum(r['launches'] * r['hbm_bytes_per_launch'] for r in rows) / sum(r['launches'] for r in rows)
-        except Exception:
-            traffic = None
+        # HBM bytes per launch of the dominant kernel: NOT measured in this run -- taken from the committed PMC passes
+        # of this command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, read side doubled per
+        # MI355X_MICROARCH.md; tools/pmc_traffic.py); null when no such file matches
+        traffic, traffic_src = None, None
+        for name in ('r02_pmc_traffic_gemm.json', 'r01_pmc_traffic_gemm.json'):
+            try:
+                pm = json.load(open(os.path.join(ROOT, 'profiles', name)))
+                rows = [v for k, v in pm.items() if k.startswith(dom)]
+                if rows and args.dtype == 'bf16' and B == 32:
+                    traffic = sum(r['launches'] * r['hbm_bytes_per_launch'] for r in rows) / sum(r['launches'] for r in rows)
+                    traffic_src = 'profiles/' + name
+                    break
+            except Exception:
+                continue
+        par = f'dp{world}'
+        if world > 1:
+            par += f' ({"RCCL" if backend == "nccl" else backend} bucketed gradient all-reduce, backend={backend})'
         result = {
             'metric': 'depth-maps/sec (train step)', 'value': world * B * args.steps / elapsed,
             'unit': 'depth-maps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -212,15 +291,20 @@ def main():
             'config': {'workload': 'unetbaseline_model unet_256 (ngf 64) train step, BatVisionV2-shaped 256x256, '
                                    f'batch {B}/GPU, Combined L1+SIlog loss, clip 1.0, AdamW',
                        'global_batch': world * B, 'image_size': S, 'launch': 'hipGraph' if use_graph else 'launch-plan',
-                       'parallelism': f'dp{world}' + (' (RCCL bucketed grad all-reduce)' if world > 1 else '')},
+                       'parallelism': par},
             'roofline': {'bound': 'mfma', 'kernel': {'igemm': 'igemm_mfma_kernel', 'wgrad': 'wgrad_mfma_kernel'}.get(dom, dom),
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-                         'traffic': traffic, 'launches': launches,
+                         'traffic': traffic, 'traffic_source': traffic_src, 'launches': launches,
                          'avg_launch_ms': 1e3 * secs / launches,
                          'gemm_ms_per_step': 1e3 * gemm_secs / max(1, prof_steps),
                          'all_gemm_tflops': sum(v[0] for v in fam.values()) / gemm_secs / 1e12},
+            'sustained': sustained,
             'final_loss': final_loss,
         }
+        if world == 1 and not args.no_f32 and args.dtype == 'bf16':
+            del trainer, model
+            torch.cuda.empty_cache()
+            result['f32_exact'] = f32_exact_record(device, B, S, rank)
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(args.cpu_batch, args.cpu_steps, 2)
         print(json.dumps(result), flush=True)

@@ -337,6 +337,18 @@ int adn_bn_fwd_finalize(const float* partials, int64_t P, int32_t C, int64_t cou
                         const float* gamma, const float* beta, float eps, float momentum,
                         float* running_mean, float* running_var, int64_t* num_batches_tracked,
                         float* mean, float* istd, float* scale, float* shift, void* stream);
+/* Small tensors (the innermost levels): statistics finalize + apply in ONE launch, a workgroup per 32 channels and row
+ * slice (each re-reduces the partial rows of its channels: they are L2 resident).  Same arithmetic as
+ * adn_bn_fwd_finalize + adn_bn_act, resp. adn_bn_bwd_finalize + adn_bn_bwd_apply (g in place).  C % 32 == 0. */
+int adn_bn_fwd_fused(const float* partials, int64_t P, int32_t C, int64_t count, const float* gamma,
+                     const float* beta, float eps, float momentum, float* running_mean,
+                     float* running_var, int64_t* num_batches_tracked, float* mean, float* istd,
+                     float* scale, float* shift, const void* z, int64_t pixels, int32_t dtype, float slope,
+                     void* out_leaky, void* out_relu, void* stream);
+int adn_bn_bwd_fused(const float* partials, int64_t P, int32_t C, int64_t count, float* dgamma,
+                     float* dbeta, void* g, const void* z, int64_t pixels, int32_t dtype,
+                     const float* scale, const float* mean, const float* istd, void* stream);
+
 /* Eval-mode: scale/shift from running statistics. */
 int adn_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, int32_t C, float* scale, float* shift,
@@ -361,7 +373,9 @@ int adn_bn_bwd_apply(void* g, const void* z, int64_t pixels, int32_t C, int32_t 
 int adn_loss_stats(const float* pred, const float* gt, int64_t n, float scale, int32_t mask_mode,
                    float eps, double* stats, void* workspace, int64_t workspace_bytes, void* stream);
 int64_t adn_loss_workspace_bytes(int64_t n);
-/* criterion: 0 L1, 1 SIlog, 2 Combined.  loss_out (f32 scalar) and grad (f32, d loss/d pred). */
+/* criterion: 0 L1, 1 SIlog, 2 Combined (l1_weight * L1 + silog_weight * SIlog), 4 masked MSE scaled by l1_weight (its
+ * statistics are taken with mask_mode | 4: sum of squared instead of absolute errors).  loss_out (f32 scalar) and grad
+ * (f32, d loss/d pred). */
 int adn_loss_finish(const float* pred, const float* gt, int64_t n, float scale, int32_t mask_mode,
                     float eps, const double* stats, int32_t criterion, float l1_weight,
                     float silog_weight, float silog_lambda, float* loss_out, float* grad,

@@ -257,9 +257,10 @@ def distillation_loss(output, gt, valid, lambda_task=2.0, lambda_response=0.3, l
 
 
 # ---- Base + Residual model (base_residual_model.py, utils_base_residual_loss.py) ----------------------------------------
-def base_residual_forward(sd, x, max_depth=30.0, training=True):
-    """BaseResidualDepthNet.forward (base_residual_model.py:151-202) for output_size == input size: shared encoder, base
-    decoder -> sigmoid * max_depth, residual decoder -> tanh * 0.3 * max_depth, final = clamp(base + residual)."""
+def base_residual_forward(sd, x, max_depth=30.0, training=True, output_size=None):
+    """BaseResidualDepthNet.forward (base_residual_model.py:151-211): shared encoder, base decoder -> sigmoid * max_depth,
+    residual decoder -> tanh * 0.3 * max_depth, each ACTIVATED map resized (bilinear, align_corners=False) when its size
+    differs from output_size (:185-188, :206-209; None = same size), final = clamp(base + residual)."""
     new_stats = {}
     feats = encoder(sd, '', _q(x), training, new_stats)
 
@@ -272,6 +273,9 @@ def base_residual_forward(sd, x, max_depth=30.0, training=True):
     b, r = dec('base'), dec('res')
     base = torch.sigmoid(F.conv2d(b, sd['base_head.weight'], sd['base_head.bias'])) * max_depth
     residual = torch.tanh(F.conv2d(r, sd['res_head.weight'], sd['res_head.bias'])) * (max_depth * 0.3)
+    if output_size is not None and tuple(base.shape[-2:]) != (output_size, output_size):
+        base = F.interpolate(base, size=(output_size, output_size), mode='bilinear', align_corners=False)
+        residual = F.interpolate(residual, size=(output_size, output_size), mode='bilinear', align_corners=False)
     return base, residual, torch.clamp(base + residual, 0, max_depth), new_stats
 
 

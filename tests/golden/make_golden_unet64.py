@@ -1,0 +1,112 @@
+"""Reference-generated fixture for the FULL-WIDTH U-Net (unet_256, ngf 64: the MFMA path of libadn), made by importing the
+reference in the build container:
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_unet64.py
+
+Entry points exercised (file:line in /root/reference): models/unetbaseline_model.py:84 define_G; utils_loss.py:9
+SIlogLoss; train.py:646-691 (masked Combined loss, backward, clip_grad_norm_(1.0), AdamW(lr) step).
+
+54.4 M parameters are not stored: the weights are regenerated from torch.manual_seed(0) by the mirror's define_G (its
+same-seed-same-weights property is pinned separately, tests/test_gpu_unet.py) and checked here against per-tensor
+checksums.  Stored: inputs are regenerated from their seeds too; the reference's train-mode prediction for B = 4
+(config 1's batch), the loss, d loss / d pred, per-tensor gradient norms + a fixed 512-element sample of every gradient,
+the clipped global norm, a 512-element sample of every parameter after the AdamW step, all BatchNorm running statistics
+after the step, and 8192 sampled points of the eval-mode prediction at B = 32 (the headline batch).
+"""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+sys.path.insert(0, '/root/reference')
+from models.unetbaseline_model import define_G          # noqa: E402
+from utils_loss import SIlogLoss                         # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+L1_W, SILOG_W, SILOG_LAMBDA, LR = 0.237, 0.637, 0.869, 0.002   # conf/mode/train.yaml
+NS = 512
+
+
+def synth_batch(B, S, seed):
+    g = torch.Generator().manual_seed(seed)
+    audio = torch.rand(B, 2, S, S, generator=g)
+    gt = 30.0 * torch.rand(B, 1, S, S, generator=g)
+    gt[gt < 3.0] = 0.0
+    return audio, gt
+
+
+def sample_idx(numel, key):
+    """Fixed sample positions of a tensor (same generator in the test)."""
+    g = torch.Generator().manual_seed(hash_key(key))
+    return torch.randint(0, numel, (min(NS, numel),), generator=g)
+
+
+def hash_key(key):
+    h = 0
+    for ch in key:
+        h = (h * 131 + ord(ch)) % (2 ** 31 - 1)
+    return h
+
+
+def main():
+    torch.set_num_threads(8)
+    cfg = SimpleNamespace(dataset=SimpleNamespace(depth_norm=False, max_depth=30.0))
+    torch.manual_seed(0)
+    model = define_G(cfg, input_nc=2, output_nc=1, ngf=64, netG='unet_256', norm='batch', use_dropout=False,
+                     init_type='normal', init_gain=0.02, gpu_ids=[])
+    with torch.no_grad():
+        model.model.model[3].bias.fill_(1.0)        # see make_golden.py: keeps SIlog away from log(0)
+    out = {}
+    for k, v in model.state_dict().items():
+        if v.dtype.is_floating_point:
+            out['init_sum/' + k] = np.float64(v.double().sum().item())
+            out['init_abs/' + k] = np.float64(v.double().abs().sum().item())
+    # eval-mode prediction at the headline batch (initial running statistics)
+    a32, _ = synth_batch(32, 256, 4321)
+    model.eval()
+    with torch.no_grad():
+        p32 = model(a32)
+    g = torch.Generator().manual_seed(99)
+    idx = torch.randint(0, p32.numel(), (8192,), generator=g)
+    out['eval32_idx'] = idx.numpy()
+    out['eval32_val'] = p32.view(-1)[idx].numpy()
+    out['eval32_absmean'] = np.float64(p32.abs().mean().item())
+    # one training step, B = 4 (train.py:633-691)
+    audio, gt = synth_batch(4, 256, 1234)
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=LR)
+    opt.zero_grad()
+    pred = model(audio)
+    valid = gt != 0.0
+    loss = L1_W * torch.nn.L1Loss()(pred[valid], gt[valid]) + SILOG_W * SIlogLoss(lambda_scale=SILOG_LAMBDA)(pred[valid], gt[valid])
+    pred.retain_grad()
+    loss.backward()
+    out['pred_train'] = pred.detach().numpy()
+    out['pred_grad'] = pred.grad.detach().numpy()
+    out['loss'] = np.float64(loss.item())
+    for k, prm in model.named_parameters():
+        gflat = prm.grad.detach().view(-1)
+        si = sample_idx(gflat.numel(), k)
+        out['gnorm/' + k] = np.float64(gflat.double().norm().item())
+        out['gsample/' + k] = gflat[si].numpy()
+    tn = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
+    out['grad_norm'] = np.float64(tn.item())
+    before = {k: p.detach().clone() for k, p in model.named_parameters()}
+    opt.step()
+    for k, prm in model.named_parameters():
+        si = sample_idx(prm.numel(), k)
+        out['p0sample/' + k] = before[k].view(-1)[si].numpy()
+        out['p1sample/' + k] = prm.detach().view(-1)[si].numpy()
+    for k, v in model.state_dict().items():
+        if 'running_' in k or 'num_batches' in k:
+            out['sd1/' + k] = v.detach().clone().numpy()
+    out['hyper'] = np.array([LR, 30.0, L1_W, SILOG_W, SILOG_LAMBDA], dtype=np.float64)
+    path = os.path.join(HERE, 'unet256_ngf64.npz')
+    np.savez_compressed(path, **out)
+    print('unet256_ngf64 loss', loss.item(), 'grad_norm', tn.item(), 'bytes', os.path.getsize(path))
+
+
+if __name__ == '__main__':
+    main()

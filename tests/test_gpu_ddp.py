@@ -241,3 +241,58 @@ def test_torchrun_entry_point_two_ranks(tmp_path):
     ck = torch.load(os.path.join(tmp_path, 'results', 'ddp', 'best_model.pth'), map_location='cpu')
     assert ck['epoch'] == 1 and ck['optimizer_state_dict']['step'] == 2
     assert all(torch.isfinite(v).all() for v in ck['model_state_dict'].values() if v.is_floating_point())
+
+
+# ---- RCCL itself: backend 'nccl' (= RCCL on ROCm), world size 1, in a fresh child process ----------------------------
+def _rccl_worker(port, dtype_name, plan, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        from audio_depth_estimation_amd.ddp import GradientAllReducer
+        from audio_depth_estimation_amd.engine import FusedTrainer
+        assert dist.get_backend() == 'nccl'
+        dtype = getattr(torch, dtype_name)
+        results = []
+        for use_ddp in (True, False):
+            model, targs, cin = _make('unet')
+            model.compute_dtype = dtype
+            red = GradientAllReducer(bucket_bytes=1 << 20) if use_ddp else None     # several buckets for unet_128
+            tr = FusedTrainer(model.engine(), ddp=red, **targs)
+            if use_ddp:
+                model.engine().bind_parameters()
+                red.broadcast_parameters(model.engine().flat_p)
+                if plan:
+                    tr.enable_launch_plan(after_steps=1)          # collectives replayed from inside the launch plan
+            x, gt = _shard(0, cin)
+            losses = []
+            for _ in range(4):
+                loss, _ = tr.step(x, gt)
+                losses.append(float(loss))
+            torch.cuda.synchronize()
+            nb = len(red.buckets) if use_ddp else 0
+            results.append((losses, model.engine().flat_p.detach().cpu().numpy().tobytes(), nb))
+        out.put(results)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('dtype_name', ['float32', 'bfloat16'])
+@pytest.mark.parametrize('plan', [False, True])
+def test_rccl_backend_world1_matches_plain_step(dtype_name, plan):
+    """The data-parallel step over the REAL RCCL backend (torch.distributed 'nccl'): asynchronous bucketed all-reduce
+    launched from the gradient-ready watermark on RCCL's stream, finish() ordering it before the clip / optimizer
+    kernels, the 4-double loss-statistics all-reduce on device doubles.  With one rank every collective is the
+    identity, so four steps must leave bit-identical losses and parameters to the plain (no reducer) trainer -- any
+    missing stream dependency between RCCL's stream and the compute stream would show as a difference."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), dtype_name, plan, q))
+    p.start()
+    (l_ddp, p_ddp, nb), (l_ref, p_ref, _) = q.get(timeout=600)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert nb >= 3                                   # the exchange really was bucketed
+    assert l_ddp == l_ref
+    assert p_ddp == p_ref

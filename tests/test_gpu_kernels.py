@@ -350,3 +350,52 @@ def test_bn_finalize_many_partial_rows(P):
     k.bn_bwd_finalize(part.to(DEV).contiguous(), P, C, cnt, dgamma, dbeta, coef)
     assert rel_err(dbeta, s1) <= 1e-6 and rel_err(dgamma, s2) <= 1e-6
     assert rel_err(coef[:C], s1 / cnt) <= 1e-6 and rel_err(coef[C:], s2 / cnt) <= 1e-6
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(37, 7, 64), (512, 2048, 512), (3, 130, 96)])
+def test_bn_fused_small_tensor_kernels(dtype, shape):
+    """adn_bn_fwd_fused / adn_bn_bwd_fused (one launch) == the finalize + apply pairs on the same partial rows."""
+    k = K()
+    P, pixels, C = shape
+    g = torch.Generator().manual_seed(P + C)
+    part = torch.randn(P, 2, C, generator=g)
+    part[:, 1] = part[:, 1].abs() * 50 + 3
+    part = part.to(DEV).contiguous()
+    z = torch.randn(pixels, C, generator=g).to(dtype).to(DEV)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+    cnt = pixels
+
+    def run(fused):
+        mean, istd, scale, shift = (torch.empty(C, device=DEV) for _ in range(4))
+        rm, rv, nbt = torch.zeros(C, device=DEV), torch.ones(C, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV)
+        lk, rl = torch.empty_like(z), torch.empty_like(z)
+        if fused:
+            k.bn_fwd_fused(part, P, C, cnt, gamma, beta, 1e-5, 0.1, rm, rv, nbt, mean, istd, scale, shift, z, pixels, 0.2,
+                           lk, rl)
+        else:
+            k.bn_fwd_finalize(part, P, C, cnt, gamma, beta, 1e-5, 0.1, rm, rv, nbt, mean, istd, scale, shift)
+            k.bn_act(z, pixels, C, scale, shift, 0.2, lk, rl)
+        return mean, istd, scale, shift, rm, rv, nbt, lk, rl
+
+    a, b = run(True), run(False)
+    for x, y in zip(a[:6], b[:6]):
+        assert rel_err(x, y) <= 1e-6
+    assert int(a[6]) == int(b[6]) == 1
+    assert rel_err(a[7], b[7]) <= TOL_T_OUT[dtype] and rel_err(a[8], b[8]) <= TOL_T_OUT[dtype]
+    # a single output is allowed
+    lk2 = torch.empty_like(z)
+    k.bn_fwd_fused(part, P, C, cnt, gamma, beta, 1e-5, 0.1, None, None, None, a[0].clone(), a[1].clone(), a[2].clone(),
+                   a[3].clone(), z, pixels, 0.0, None, lk2)
+    assert torch.equal(lk2, a[8])
+    # backward
+    mean, istd, scale = a[0], a[1], a[2]
+    gsrc = torch.randn(pixels, C, generator=g).to(dtype).to(DEV)
+    g1, g2 = gsrc.clone(), gsrc.clone()
+    dg1, db1, dg2, db2 = (torch.empty(C, device=DEV) for _ in range(4))
+    coef = torch.empty(2 * C, device=DEV)
+    k.bn_bwd_fused(part, P, C, cnt, dg1, db1, g1, z, pixels, scale, mean, istd)
+    k.bn_bwd_finalize(part, P, C, cnt, dg2, db2, coef)
+    k.bn_bwd_apply(g2, z, pixels, C, scale, mean, istd, coef)
+    assert rel_err(dg1, dg2) <= 1e-6 and rel_err(db1, db2) <= 1e-6
+    assert rel_err(g1, g2) <= TOL_T_OUT[dtype]
