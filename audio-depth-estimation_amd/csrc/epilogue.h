@@ -187,3 +187,31 @@ __device__ __forceinline__ void epi_vec8(int epi, const AdnEpiSeg& sg, const Epi
     store8<float>(sg.out0, idx, o);
   }
 }
+
+// BWD epilogue (bf16) on operand chunks that were loaded ahead of the K loop: same arithmetic as the ADN_EPI_BWD branch
+// of epi_vec8.
+__device__ __forceinline__ void epi_bwd_pre8(const AdnEpiSeg& sg, const EpiCols& c, int64_t op, int nl, const float* v,
+                                             const u32x4_t& ref_raw, const u32x4_t& old_raw, const u32x4_t& z_raw,
+                                             float* s1, float* s2) {
+  const int64_t idx = op * sg.channels + nl;
+  float r[8], g[8];
+  Chunk<uint16_t>::unpack(ref_raw, r);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) g[e] = v[e] * (r[e] > 0.f ? 1.0f : sg.slope);
+  if (sg.accumulate) {
+    float old[8];
+    Chunk<uint16_t>::unpack(old_raw, old);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] += old[e];
+  }
+  store8<uint16_t>(sg.out0, idx, g);
+  if (sg.partials) {
+    float z[8];
+    Chunk<uint16_t>::unpack(z_raw, z);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      s1[e] += g[e];
+      s2[e] += g[e] * ((z[e] - c.a[e]) * c.b[e]);
+    }
+  }
+}

@@ -57,6 +57,8 @@ struct KParams {
   AdnEpiSeg seg[2];
   float* slab;    // split-K / generic scratch
   unsigned rec_a, rec_b;   // buffer-descriptor record bytes of the gathered / weight operands (0 = timing-only build)
+  int lgW, lgH;            // log2 of Ws / Hs when both are powers of two (every U-Net level), else -1: the pixel decode
+                           // of the tile prologue / epilogue then uses shifts instead of ~40-instruction integer divisions
 };
 
 
@@ -115,6 +117,20 @@ __global__ __launch_bounds__(BM * NWN, 2) void igemm_mfma_kernel(KParams p) {
   const int Hs = p.Hs, Ws = p.Ws;
   const int Hl = 2 * Hs, Wl = 2 * Ws;
   const int Cin = p.C0 + p.C1;
+  const bool pow2 = p.lgW >= 0;                      // kernel-uniform
+  // small-grid pixel m -> (image b, row y, column x)
+  auto decode = [&](int m, int& b, int& y, int& x) {
+    if (pow2) {
+      x = m & (Ws - 1);
+      y = (m >> p.lgW) & (Hs - 1);
+      b = m >> (p.lgW + p.lgH);
+    } else {
+      b = m / (Hs * Ws);
+      const int rem = m - b * (Hs * Ws);
+      y = rem / Ws;
+      x = rem - y * Ws;
+    }
+  };
 
   // ---- loader geometry (LDS-DMA: buffer_load_dwordx4 ... lds writes wave-uniform base + lane*16) ----
   // Wave w fills rows j*RPASS + w*8 .. +8 of each tile with ONE 1-KiB wave-instruction: lane l lands on row
@@ -147,24 +163,22 @@ __global__ __launch_bounds__(BM * NWN, 2) void igemm_mfma_kernel(KParams p) {
     const int m = tile_m * BM + lrow + RPASS * j;
     const bool okm = m < p.Msmall;
     const int mm = okm ? m : 0;
-    const int b = mm / (Hs * Ws);
-    const int rem = mm - b * (Hs * Ws);
-    const int y = rem / Ws;
-    const int x = rem - y * Ws;
+    int b, y, x;
+    decode(mm, b, y, x);
     unsigned mask = 0;
     int pix;
+    // tap validity bit masks: a tap is padding only at the image border, so the 16 (S2) / 4 (T2) per-tap range checks
+    // reduce to four border compares selecting constant bit groups
     if constexpr (GEOM == ADN_GEMM_S2) {
       pix = (b * Hl + 2 * y) * Wl + 2 * x;                   // tap (ky,kx) adds (ky-1)*Wl + (kx-1)
-      for (int t = 0; t < 16; ++t) {
-        const int iy = 2 * y - 1 + (t >> 2), ix = 2 * x - 1 + (t & 3);
-        if ((unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl) mask |= 1u << t;
-      }
+      mask = 0xffffu & ~((y == 0 ? 0x000fu : 0u) | (y == Hs - 1 ? 0xf000u : 0u) | (x == 0 ? 0x1111u : 0u) |
+                         (x == Ws - 1 ? 0x8888u : 0u));
     } else if constexpr (GEOM == ADN_GEMM_T2) {
       pix = (b * Hs + y) * Ws + x;                            // tap (ty,tx) adds dy*Ws + dx
-      for (int t = 0; t < 4; ++t) {
-        const int iy = y + adn_t2_dy(ph, t >> 1), ix = x + adn_t2_dy(pw, t & 1);
-        if ((unsigned)iy < (unsigned)Hs && (unsigned)ix < (unsigned)Ws) mask |= 1u << t;
-      }
+      // phase bit 0: tap index 1 reaches back (dy = -1), phase bit 1: tap index 0 reaches forward (dy = +1)
+      const unsigned ybad = ph == 0 ? (y == 0 ? 0xcu : 0u) : (y == Hs - 1 ? 0x3u : 0u);          // t = ty*2 + tx
+      const unsigned xbad = pw == 0 ? (x == 0 ? 0xau : 0u) : (x == Ws - 1 ? 0x5u : 0u);
+      mask = 0xfu & ~(ybad | xbad);
     } else {
       pix = (b * Hs + y) * Ws + x;                            // tap (ky,kx) adds (ky-kpad)*Ws + (kx-kpad)
       for (int t = 0; t < ntaps; ++t) {
@@ -258,6 +272,48 @@ __global__ __launch_bounds__(BM * NWN, 2) void igemm_mfma_kernel(KParams p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+  // ---- BWD epilogue operands requested up front (bf16, unsplit) ----
+  // The BWD epilogue reads up to three tensors per output element (activation sign reference, the running gradient it
+  // accumulates into, the raw conv output for the BatchNorm-backward sums): issued behind the K loop they are a fully
+  // exposed HBM round trip per tile (the two workgroups of a CU run in phase: L2 dgrad 50 us with a store-only epilogue,
+  // 85 us with this one).  Their addresses do not depend on the GEMM result, so the 16-byte chunks of this thread's
+  // epilogue rows are loaded NOW and ride in registers under the K loop (<= 96 VGPRs; the kernel runs 2 waves per SIMD).
+  constexpr int CPR = BN / 8;        // 8-channel column groups per row
+  constexpr int RSTEP = NTHR / CPR;  // rows covered per pass
+  constexpr int RPT = BM / RSTEP;    // rows per thread
+  const int e_cg = tid % CPR;
+  const int e_rsub = tid / CPR;
+  const int e_n0 = tile_n * BN + e_cg * 8;
+  constexpr bool PRE_OK = sizeof(T) == 2;
+  const bool pre_on = PRE_OK && p.epi == ADN_EPI_BWD && p.nsplit == 1;
+  u32x4_t pre_r[RPT], pre_o[RPT], pre_z[RPT];
+  if constexpr (PRE_OK) {
+    if (pre_on) {
+      const bool first = e_n0 < p.seg[0].channels;
+      const AdnEpiSeg& sq = first ? p.seg[0] : p.seg[1];
+      const int nl0 = first ? e_n0 : e_n0 - p.seg[0].channels;
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        const int m = tile_m * BM + e_rsub + RSTEP * k;
+        pre_r[k] = pre_o[k] = pre_z[k] = u32x4_t{0u, 0u, 0u, 0u};
+        if (m < p.Msmall) {
+          int64_t op;
+          if constexpr (GEOM != ADN_GEMM_T2) {
+            op = m;
+          } else {
+            int b, i, jx;
+            decode(m, b, i, jx);
+            op = ((int64_t)b * Hl + 2 * i + ph) * Wl + 2 * jx + pw;
+          }
+          const int64_t idx = op * sq.channels + nl0;
+          pre_r[k] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const uint16_t*>(sq.ref) + idx);
+          if (sq.accumulate) pre_o[k] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const uint16_t*>(sq.out0) + idx);
+          if (sq.partials) pre_z[k] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const uint16_t*>(sq.z) + idx);
+        }
+      }
+    }
+  }
+
   // ---- pipeline: STAGES-1 steps of LDS-DMA in flight; one raw barrier per K-step ----
   // At the top of step s the stages s .. s+STAGES-2 have been issued.  "s_waitcnt vmcnt(LOADS*(STAGES-2))"
   // retires this wave's DMA of stage s (vmcnt counts in issue order), the barrier then (a) makes every
@@ -313,12 +369,9 @@ __global__ __launch_bounds__(BM * NWN, 2) void igemm_mfma_kernel(KParams p) {
         ct[(wm * 64 + i * 16 + 4 * fq + r) * LDC + wn * WN + j * 16 + frow] = acc[i][j][r];
   __syncthreads();
 
-  constexpr int CPR = BN / 8;        // 8-channel column groups per row
-  constexpr int RSTEP = NTHR / CPR;  // rows covered per pass
-  constexpr int RPT = BM / RSTEP;    // rows per thread
-  const int cg = tid % CPR;
-  const int rsub = tid / CPR;
-  const int n0 = tile_n * BN + cg * 8;
+  const int cg = e_cg;
+  const int rsub = e_rsub;
+  const int n0 = e_n0;
 
   int epi = p.epi;
   AdnEpiSeg sg;
@@ -353,10 +406,8 @@ __global__ __launch_bounds__(BM * NWN, 2) void igemm_mfma_kernel(KParams p) {
       if constexpr (GEOM != ADN_GEMM_T2) {
         op = m;
       } else {
-        const int b = m / (Hs * Ws);
-        const int rem = m - b * (Hs * Ws);
-        const int i = rem / Ws;
-        const int jx = rem - i * Ws;
+        int b, i, jx;
+        decode(m, b, i, jx);
         op = ((int64_t)b * Hl + 2 * i + ph) * Wl + 2 * jx + pw;
       }
       float v[8];
@@ -366,6 +417,12 @@ __global__ __launch_bounds__(BM * NWN, 2) void igemm_mfma_kernel(KParams p) {
       for (int e = 0; e < 4; ++e) {
         v[e] = v0[e];
         v[4 + e] = v1[e];
+      }
+      if constexpr (PRE_OK) {
+        if (pre_on) {
+          epi_bwd_pre8(sg, cols, op, nl, v, pre_r[k], pre_o[k], pre_z[k], s1, s2);
+          continue;
+        }
       }
       epi_vec8<T>(epi, sg, cols, op, nl, v, s1, s2);
     }
@@ -637,6 +694,12 @@ int run(const AdnIgemmDesc* d, const Plan& pl, hipStream_t st) {
   kp.seg[0] = d->seg[0];
   kp.seg[1] = d->seg[1];
   kp.slab = reinterpret_cast<float*>(d->workspace);
+  {
+    auto lg2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
+    kp.lgW = lg2(d->Ws);
+    kp.lgH = lg2(d->Hs);
+    if (kp.lgW < 0 || kp.lgH < 0) kp.lgW = kp.lgH = -1;
+  }
   kp.rec_a = tune().noa ? 0u : 0x7ffffff0u;
   kp.rec_b = tune().nob ? 0u : 0x7ffffff0u;
   if (pl.mfma) {
