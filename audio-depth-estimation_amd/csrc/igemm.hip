@@ -25,8 +25,9 @@ namespace {
 //   ADN_IGEMM_BM / ADN_IGEMM_BN / ADN_IGEMM_NS  force the tile rows / columns, cap the split-K count
 //   ADN_IGEMM_NOA / ADN_IGEMM_NOB               timing-only builds: the gathered / weight operand is read through a
 //                                               zero-record descriptor (every load dropped, zeros in LDS; wrong results)
+//   ADN_IGEMM_SKIP                              timing-only builds: bit 0 / 1 = the operand's LDS-DMA is not issued at all
 struct Tune {
-  int bm = 0, bn = 0, ns = 0, noa = 0, nob = 0;
+  int bm = 0, bn = 0, ns = 0, noa = 0, nob = 0, skip = 0, patch = 1;
 };
 const Tune& tune() {
   static Tune t;
@@ -37,6 +38,8 @@ const Tune& tune() {
     if (const char* e = getenv("ADN_IGEMM_NS")) t.ns = atoi(e);
     if (const char* e = getenv("ADN_IGEMM_NOA")) t.noa = atoi(e);
     if (const char* e = getenv("ADN_IGEMM_NOB")) t.nob = atoi(e);
+    if (const char* e = getenv("ADN_IGEMM_SKIP")) t.skip = atoi(e);
+    if (const char* e = getenv("ADN_IGEMM_PATCH")) t.patch = atoi(e);
   });
   return t;
 }
@@ -57,6 +60,7 @@ struct KParams {
   AdnEpiSeg seg[2];
   float* slab;    // split-K / generic scratch
   unsigned rec_a, rec_b;   // buffer-descriptor record bytes of the gathered / weight operands (0 = timing-only build)
+  int skip;                // timing-only builds: bit 0 / 1 = do not even ISSUE the gathered / weight operand's LDS-DMA
   int lgW, lgH;            // log2 of Ws / Hs when both are powers of two (every U-Net level), else -1: the pixel decode
                            // of the tile prologue / epilogue then uses shifts instead of ~40-instruction integer divisions
 };
@@ -230,6 +234,7 @@ __global__ __launch_bounds__(BM * NWN, 2) void igemm_mfma_kernel(KParams p) {
       else shift = (tap / ks) * Ws + tap % ks;
       const int soff = (shift * Cs + coff) * ESZ;
       const unsigned lane_c = (unsigned)(lc * EPC * ESZ);
+      if (!(p.skip & 1))
 #pragma unroll
       for (int j = 0; j < APASS; ++j) {
         const unsigned base = (second ? roff1[j] : roff0[j]) + lane_c;
@@ -261,6 +266,7 @@ __global__ __launch_bounds__(BM * NWN, 2) void igemm_mfma_kernel(KParams p) {
       }
     }
     const int soffb = s * 128;
+    if (!(p.skip & 2))
 #pragma unroll
     for (int j = 0; j < BPASS; ++j)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lptr_t)(bdst + j * (RPASS * 128)), 16, boff[j], soffb, 0, 0);
@@ -465,6 +471,323 @@ __global__ __launch_bounds__(BM * NWN, 2) void igemm_mfma_kernel(KParams p) {
 #endif
 }
 
+
+// =====================================================================================================================
+// Patch-staged variant (bf16, wide channels, unsplit): the gathered operand goes through LDS as an input PATCH.
+//
+// Why: timing-only builds of the kernel above (ADN_IGEMM_SKIP) showed that the K loop is paced by the LDS-DMA of the
+// GATHERED operand: not issuing it at all gives -27 ... -34 % on the wide layers (L2 forward 48 -> 35 us, D1 forward
+// 121 -> 80 us), not issuing the weights only -7 ... -15 %.  Staging taps as K-steps fetches every input pixel 4 times
+// (overlapping 4 x 4 stride-2 windows, resp. 2 x 2 windows of a transposed-conv phase).  Here a workgroup owns an
+// 8 x 16 block of output pixels of ONE image and stages, per 32-channel chunk, the input pixels that block needs ONCE:
+//   S2 (k4 s2 p1 conv, dgrad of the transposed conv): an 18 x 34 patch, loaded in two halves by input-row parity (a half
+//      serves the two kernel rows ky of that parity = 8 taps = 4 K-steps), even / odd input columns in separate planes
+//      so that the 16 output columns of a fragment read 16 CONSECUTIVE 64-byte LDS pixels for every tap;
+//   T2 (one phase of the transposed conv, dgrad of the conv): a 9 x 17 patch per chunk (4 taps = 2 K-steps).
+// A K-step = 2 taps x 32 channels (the same 32 MFMAs per wave and barrier as above); the weights of the step come as
+// [2 taps][BN rows][64 B].  LDS-DMA wave-instructions per wave and step: 4 (weights) + 1.25 (patch) instead of 8; gathered
+// bytes per step 4.9 KiB instead of 16 KiB.  64-byte pixels: the 16-byte chunk index is XOR-ed with ((pixel >> 2) & 1) << 1
+// (on the DMA source side), which makes the ds_read_b128 fragment reads conflict free at every alignment (brute-forced).
+// The next patch (half) is loaded into the other patch buffer during the steps of the current one; every step ends in
+// "s_waitcnt vmcnt(0); s_barrier", so it has landed before its first use.
+template <int BN, int GEOM>
+__global__ __launch_bounds__(256, 2) void igemm_patch_kernel(KParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef uint16_t T;
+  constexpr int BM = 128, NWN = 2, NTHR = 256, TH = 8, TW = 16;
+  constexpr int WN = BN / NWN, NT = WN / 16, MT = 4;
+  constexpr bool S2 = GEOM == ADN_GEMM_S2;
+  constexpr int MW = TW + 1;                                  // patch columns per plane
+  constexpr int SEG_PIX = S2 ? 2 * (TH + 1) * MW : (TH + 1) * MW;   // pixels of one patch segment (306 / 153)
+  constexpr int SEG_STEPS = S2 ? 4 : 2;                       // K-steps served by one segment
+  constexpr int PPIECES = (SEG_PIX + 15) / 16;                // 1-KiB DMA pieces per segment (20 / 10)
+  constexpr int PK = (PPIECES + 3) / 4;                       // pieces per wave (5 / 3)
+  constexpr int PBUF = PPIECES * 1024;
+  constexpr int BPT = BN / 16;                                // weight pieces per tap
+  constexpr int BK_ = 2 * BPT / 4;                            // weight pieces per wave and step (4 / 2)
+  constexpr int BBUF = 2 * BN * 64;                           // one weight stage: [2 taps][BN][64 B]
+  constexpr int LDC = BN + 4;
+  constexpr unsigned OOB = 0x80000000u;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Pl = smem;                       // [2][PBUF]
+  char* Bl = smem + 2 * PBUF;            // [2][BBUF]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  constexpr int NPH = S2 ? 1 : 4;
+  const int nwg = p.tiles_m * p.tiles_n * NPH;
+  const int wg0 = xcd_remap(blockIdx.x, nwg);
+  const int phase = wg0 % NPH;
+  const int wg = wg0 / NPH;
+  const int tile_n = wg % p.tiles_n;
+  const int tile_m = wg / p.tiles_n;
+  const int ph = phase >> 1, pw = phase & 1;
+  const int Hs = p.Hs, Ws = p.Ws, Hl = 2 * Hs, Wl = 2 * Ws;
+  const int Cin = p.C0 + p.C1;
+  // tile -> (image, first output row, first output column) on the small grid
+  const int tpr = Ws / TW, tpi = (Hs / TH) * tpr;
+  const int tb = tile_m / tpi, trem = tile_m - tb * tpi;
+  const int oy0 = (trem / tpr) * TH, ox0 = (trem % tpr) * TW;
+  // gathered image: S2 gathers from the large grid (2Hs x 2Ws), T2 from the small grid
+  const int Hg = S2 ? Hl : Hs, Wg = S2 ? Wl : Ws;
+  const int ymin = S2 ? 0 : (ph == 0 ? -1 : 0), xmin = S2 ? 0 : (pw == 0 ? -1 : 0);
+
+  // ---- patch loader geometry (per lane, constant over the K loop) ----
+  // piece pi = wave + 4k covers LDS pixels q = 16 pi .. 16 pi + 15; lane l -> pixel 16 pi + (l >> 2), physical chunk l & 3
+  unsigned ppix[PK];                         // gathered pixel index (+ bshift) of this lane's pixel of piece k
+  unsigned pmask = 0;                        // bit 2k: valid for row parity 0 (T2: valid), bit 2k+1: row parity 1
+  const int bshift = Wg + 1;                 // descriptor base shifted back: every offset >= 0
+#pragma unroll
+  for (int k = 0; k < PK; ++k) {
+    const int q = 16 * (wave + 4 * k) + (lane >> 2);
+    int iy, ix;
+    bool ok0, ok1;
+    if constexpr (S2) {
+      const int par = q / ((TH + 1) * MW), rem = q - par * ((TH + 1) * MW);
+      const int hr = rem / MW, m = rem - hr * MW;
+      iy = 2 * oy0 - 1 + 2 * hr;             // row of parity 0; parity 1 is the next row
+      ix = 2 * ox0 - 1 + 2 * m + par;
+      const bool okx = (unsigned)ix < (unsigned)Wg && q < SEG_PIX;
+      ok0 = okx && (unsigned)iy < (unsigned)Hg;
+      ok1 = okx && (unsigned)(iy + 1) < (unsigned)Hg;
+    } else {
+      const int hr = q / MW, m = q - hr * MW;
+      iy = oy0 + hr + ymin;
+      ix = ox0 + m + xmin;
+      ok0 = ok1 = (unsigned)ix < (unsigned)Wg && (unsigned)iy < (unsigned)Hg && q < SEG_PIX;
+    }
+    ppix[k] = (unsigned)((tb * Hg + iy) * Wg + ix + bshift);
+    pmask |= (ok0 ? 1u : 0u) << (2 * k) | (ok1 ? 2u : 0u) << (2 * k);
+  }
+  // ---- weight loader geometry: piece pid = wave + 4k of a step's [2][BN][64 B] tile ----
+  unsigned bvo[BK_];
+  const int ktot = p.wstride;
+#pragma unroll
+  for (int k = 0; k < BK_; ++k) {
+    const int pid = wave + 4 * k;
+    const int tsel = pid / BPT, row = (pid % BPT) * 16 + (lane >> 2);
+    const int lc = (lane & 3) ^ (((row >> 2) & 1) << 1);
+    bvo[k] = (unsigned)(((tile_n * BN + row) * ktot + tsel * Cin + lc * 8) * 2);
+  }
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(reinterpret_cast<const char*>(p.in0) - (int64_t)bshift * p.C0 * 2), 0, p.rec_a, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(reinterpret_cast<const char*>(p.C1 ? p.in1 : p.in0) - (int64_t)bshift * p.C1 * 2), 0, p.rec_a, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(reinterpret_cast<const char*>(p.w) + (S2 ? 0 : (int64_t)phase * p.N * ktot * 2)), 0, p.rec_b, 0x00020000);
+
+  const int nchunks = Cin >> 5;
+  const int nseg = S2 ? 2 * nchunks : nchunks;
+  const int nsteps = nseg * SEG_STEPS;
+
+  // patch pieces of segment sg whose index k matches the step-in-segment ss (k = 0 and SEG_STEPS with ss = 0, ...)
+  auto issue_patch = [&](int sg, int ss) {
+    const int c = S2 ? sg >> 1 : sg, par = S2 ? sg & 1 : 0;
+    const int c0 = c << 5;
+    const bool second = c0 >= p.C0;
+    const int Cs = second ? p.C1 : p.C0;
+    const int coff = second ? c0 - p.C0 : c0;
+    const int soff = (par * Wg * Cs + coff) * 2;
+    char* dst = Pl + (sg & 1) * PBUF + wave * 1024;
+#pragma unroll
+    for (int k = 0; k < PK; ++k) {
+      if (k % SEG_STEPS != ss) continue;
+      if (wave + 4 * k >= PPIECES) continue;
+      const bool ok = (pmask >> (2 * k + par)) & 1u;
+      // logical 16-byte chunk of this lane: physical chunk (lane & 3) ^ swizzle of its LDS pixel q = 16 (wave + 4k) + lane / 4
+      // (the wave and k terms are multiples of 16: (q >> 2) & 1 = (lane >> 4) & 1)
+      const unsigned lc16 = (unsigned)(((lane & 3) ^ (((lane >> 4) & 1) << 1)) << 4);
+      const unsigned vo = ok ? ppix[k] * (unsigned)(Cs * 2) + lc16 : OOB;
+      if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lptr_t)(dst + k * 4096), 16, vo, soff, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lptr_t)(dst + k * 4096), 16, vo, soff, 0, 0);
+    }
+  };
+  // weights of step s: taps (t0, t0 + 1), channels of the step's chunk
+  auto issue_b = [&](int s) {
+    const int sg = s / SEG_STEPS, ss = s - sg * SEG_STEPS;
+    int c, t0;
+    if constexpr (S2) {
+      c = sg >> 1;
+      const int ky = 2 * (ss >> 1) + (sg & 1);
+      t0 = ky * 4 + 2 * (ss & 1);
+    } else {
+      c = sg;
+      t0 = 2 * ss;
+    }
+    const int soff = (t0 * Cin + (c << 5)) * 2;
+    char* dst = Bl + (s & 1) * BBUF + wave * 1024;
+#pragma unroll
+    for (int k = 0; k < BK_; ++k) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lptr_t)(dst + k * 4096), 16, bvo[k], soff, 0, 0);
+  };
+
+  f32x4_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // ---- BWD epilogue operands requested up front (see the kernel above) ----
+  constexpr int CPR = BN / 8, RSTEP = NTHR / CPR, RPT = BM / RSTEP;
+  const int e_cg = tid % CPR, e_rsub = tid / CPR;
+  const int e_n0 = tile_n * BN + e_cg * 8;
+  auto row_op = [&](int row) -> int64_t {       // output pixel index of tile row `row` (row = oyl * 16 + oxl)
+    const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
+    if constexpr (S2) return ((int64_t)tb * Hs + oy) * Ws + ox;
+    else return ((int64_t)tb * Hl + 2 * oy + ph) * Wl + 2 * ox + pw;
+  };
+  // (S2 = dgrad of a transposed conv never accumulates in the U-Net: its running-gradient chunk is not kept in registers
+  //  -- 32 VGPRs that made the 128-column variant spill -- but read in the epilogue if a caller asks for it)
+  constexpr int NPO = S2 ? 1 : RPT;
+  const bool pre_on = p.epi == ADN_EPI_BWD;
+  u32x4_t pre_r[RPT], pre_o[NPO], pre_z[RPT];
+  if (pre_on) {
+    const bool first = e_n0 < p.seg[0].channels;
+    const AdnEpiSeg& sq = first ? p.seg[0] : p.seg[1];
+    const int nl0 = first ? e_n0 : e_n0 - p.seg[0].channels;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      const int64_t idx = row_op(e_rsub + RSTEP * k) * sq.channels + nl0;
+      pre_r[k] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const uint16_t*>(sq.ref) + idx);
+      pre_z[k] = u32x4_t{0u, 0u, 0u, 0u};
+      if constexpr (!S2) {
+        pre_o[k] = u32x4_t{0u, 0u, 0u, 0u};
+        if (sq.accumulate) pre_o[k] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const uint16_t*>(sq.out0) + idx);
+      }
+      if (sq.partials) pre_z[k] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const uint16_t*>(sq.z) + idx);
+    }
+  }
+
+  // ---- prologue: the whole first patch segment + the weights of step 0 ----
+#pragma unroll
+  for (int ss = 0; ss < SEG_STEPS; ++ss) issue_patch(0, ss);
+  issue_b(0);
+
+  const int frow = lane & 15, fq = lane >> 4;
+  // fragment pixel base of this lane's M-tile i: (oyl = wm*4 + i) * MW + frow
+  const int qb0 = wm * 4 * MW + frow;
+
+  int s = 0;
+  for (int sg = 0; sg < nseg; ++sg) {
+    const char* Pb = Pl + (sg & 1) * PBUF;
+#pragma unroll
+    for (int ss = 0; ss < SEG_STEPS; ++ss, ++s) {
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (s + 1 < nsteps) issue_b(s + 1);
+      if (sg + 1 < nseg) issue_patch(sg + 1, ss);
+      const char* Bb = Bl + (s & 1) * BBUF;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {                 // the step's two taps, 32 channels each
+        int qoff;
+        if constexpr (S2) qoff = ((e * (TH + 1)) + (ss >> 1)) * MW + (ss & 1);     // kx = 2 (ss & 1) + e, ky >> 1 = ss >> 1
+        else qoff = (adn_t2_dy(ph, ss) - ymin) * MW + (adn_t2_dy(pw, e) - xmin);
+        u32x4_t af[MT], bf[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int q = qb0 + i * MW + qoff;
+          af[i] = *reinterpret_cast<const u32x4_t*>(Pb + q * 64 + ((fq ^ (((q >> 2) & 1) << 1)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int row = wn * WN + j * 16 + frow;
+          bf[j] = *reinterpret_cast<const u32x4_t*>(Bb + e * (BN * 64) + row * 64 + ((fq ^ (((row >> 2) & 1) << 1)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) mma_tile<T>(af[i], bf[j], acc[i][j]);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue through LDS (as above; tile row = oyl * 16 + oxl) ----
+  float* ct = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        ct[(wm * 64 + i * 16 + 4 * fq + r) * LDC + wn * WN + j * 16 + frow] = acc[i][j][r];
+  __syncthreads();
+  const int cg = e_cg, rsub = e_rsub, n0 = e_n0;
+  const int epi = p.epi;
+  AdnEpiSeg sg2;
+  int nl;
+  if (n0 < p.seg[0].channels) {
+    sg2 = p.seg[0];
+    nl = n0;
+  } else {
+    sg2 = p.seg[1];
+    nl = n0 - p.seg[0].channels;
+  }
+  EpiCols cols;
+  epi_cols_init<T>(epi, sg2, nl, cols);
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    const int row = rsub + RSTEP * k;
+    const int64_t op = row_op(row);
+    float v[8];
+    const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(ct + row * LDC + cg * 8);
+    const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(ct + row * LDC + cg * 8 + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] = v0[e];
+      v[4 + e] = v1[e];
+    }
+    if (pre_on) {
+      if constexpr (S2) {
+        u32x4_t old = {0u, 0u, 0u, 0u};
+        if (sg2.accumulate) old = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const uint16_t*>(sg2.out0) + op * sg2.channels + nl);
+        epi_bwd_pre8(sg2, cols, op, nl, v, pre_r[k], old, pre_z[k], s1, s2);
+      } else {
+        epi_bwd_pre8(sg2, cols, op, nl, v, pre_r[k], pre_o[k], pre_z[k], s1, s2);
+      }
+    } else {
+      epi_vec8<T>(epi, sg2, cols, op, nl, v, s1, s2);
+    }
+  }
+  if ((p.seg[0].partials != nullptr || p.seg[1].partials != nullptr) && (p.epi == ADN_EPI_Z_STATS || p.epi == ADN_EPI_BWD)) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int o = CPR; o < 64; o <<= 1) {
+        s1[e] += __shfl_xor(s1[e], o, 64);
+        s2[e] += __shfl_xor(s2[e], o, 64);
+      }
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);  // [4 waves][2][BN]
+    if (lane < CPR) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[(wave * 2 + 0) * BN + cg * 8 + e] = s1[e];
+        red[(wave * 2 + 1) * BN + cg * 8 + e] = s2[e];
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int st = tid / BN, c = tid % BN;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) t += red[(w * 2 + st) * BN + c];
+      const int n = tile_n * BN + c;
+      const AdnEpiSeg& sq = (n < p.seg[0].channels) ? p.seg[0] : p.seg[1];
+      const int ncl = (n < p.seg[0].channels) ? n : n - p.seg[0].channels;
+      const int64_t P = (int64_t)phase * p.tiles_m + tile_m;
+      if (sq.partials) sq.partials[(P * 2 + st) * sq.channels + ncl] = t;
+    }
+  }
+#endif
+}
+
 // ---- generic direct path: any channel counts, one thread per output element, f32 slab out ----
 template <typename T, int GEOM>
 __global__ __launch_bounds__(256) void igemm_direct_kernel(KParams p) {
@@ -566,6 +889,7 @@ inline int reduce_rows(int64_t mout, int N) {
 struct Plan {
   bool mfma;
   bool wide;
+  bool patch;       // patch-staged kernel (bf16, wide, unsplit, image 8 x 16 tileable)
   int wstride;
   int rb;
   int bm;
@@ -632,6 +956,14 @@ bool make_plan(const AdnIgemmDesc* d, Plan* pl) {
   }
   if (tn.ns >= 1 && ns > tn.ns) ns = tn.ns;                  // tuning knob: cap on the split count
   pl->nsplit = ns;
+  // patch-staged variant: bf16, every chunk of 32 channels inside one source, images tileable by 8 x 16 output pixels,
+  // enough tiles that no split-K is wanted (ADN_IGEMM_PATCH=0 switches it off)
+  pl->patch = d->dtype == ADN_BF16 && pl->wide && ns == 1 && d->geom != ADN_GEMM_S1 && d->Hs % 8 == 0 && d->Ws % 16 == 0 &&
+              tn.patch != 0;
+  if (pl->patch) {
+    pl->bm = 128;
+    pl->tiles_m = (int)(msmall / 128);
+  }
   pl->rb = reduce_rows(pl->mout, d->N);
   if (ns > 1) {
     pl->partial_rows = adn_cdiv(pl->mout, pl->rb);
@@ -670,6 +1002,27 @@ void dispatch_mfma(const KParams& kp, const Plan& pl, hipStream_t st) {
   else dispatch_mfma2<T, GEOM, false>(kp, pl, st);
 }
 
+template <int BN, int GEOM>
+void launch_patch1(const KParams& kp, const Plan& pl, hipStream_t st) {
+  constexpr bool S2 = GEOM == ADN_GEMM_S2;
+  constexpr int ppieces = ((S2 ? 2 * 9 * 17 : 9 * 17) + 15) / 16;
+  constexpr int stage = 2 * ppieces * 1024 + 2 * 2 * BN * 64;
+  constexpr int epil = 128 * (BN + 4) * 4;
+  constexpr int lds = stage > epil ? stage : epil;
+  ADN_SET_LDS_ONCE(lds, &igemm_patch_kernel<BN, GEOM>);
+  dim3 grid(pl.tiles_m * pl.tiles_n * pl.phases, 1, 1);
+  hipLaunchKernelGGL((igemm_patch_kernel<BN, GEOM>), grid, dim3(256), lds, st, kp);
+}
+inline void launch_patch(const KParams& kp, const Plan& pl, int geom, hipStream_t st) {
+  if (geom == ADN_GEMM_S2) {
+    if (pl.bn == 128) launch_patch1<128, ADN_GEMM_S2>(kp, pl, st);
+    else launch_patch1<64, ADN_GEMM_S2>(kp, pl, st);
+  } else {
+    if (pl.bn == 128) launch_patch1<128, ADN_GEMM_T2>(kp, pl, st);
+    else launch_patch1<64, ADN_GEMM_T2>(kp, pl, st);
+  }
+}
+
 template <typename T>
 int run(const AdnIgemmDesc* d, const Plan& pl, hipStream_t st) {
   KParams kp;
@@ -702,7 +1055,11 @@ int run(const AdnIgemmDesc* d, const Plan& pl, hipStream_t st) {
   }
   kp.rec_a = tune().noa ? 0u : 0x7ffffff0u;
   kp.rec_b = tune().nob ? 0u : 0x7ffffff0u;
-  if (pl.mfma) {
+  kp.skip = tune().skip;
+  if (pl.mfma && pl.patch) {
+    if constexpr (sizeof(T) == 2) launch_patch(kp, pl, d->geom, st);
+    ADN_CHECK_LAUNCH();
+  } else if (pl.mfma) {
     if (d->geom == ADN_GEMM_S2) dispatch_mfma<T, ADN_GEMM_S2>(kp, pl, st);
     else if (d->geom == ADN_GEMM_T2) dispatch_mfma<T, ADN_GEMM_T2>(kp, pl, st);
     else dispatch_mfma<T, ADN_GEMM_S1>(kp, pl, st);
