@@ -483,7 +483,9 @@ __global__ __launch_bounds__(BM * NWN, 2) void igemm_mfma_kernel(KParams p) {
 //   S2 (k4 s2 p1 conv, dgrad of the transposed conv): an 18 x 34 patch, loaded in two halves by input-row parity (a half
 //      serves the two kernel rows ky of that parity = 8 taps = 4 K-steps), even / odd input columns in separate planes
 //      so that the 16 output columns of a fragment read 16 CONSECUTIVE 64-byte LDS pixels for every tap;
-//   T2 (one phase of the transposed conv, dgrad of the conv): a 9 x 17 patch per chunk (4 taps = 2 K-steps).
+//   T2 (one phase of the transposed conv, dgrad of the conv): a 9 x 17 patch per chunk (4 taps = 2 K-steps);
+//   S1 (3 x 3 stride-1 conv of the DoubleConv nets, forward and dgrad): a 10 x 18 patch per chunk, 9 taps = 3 K-steps of
+//      one kernel row (3 taps, 48 MFMAs per wave) each: every input pixel is fetched once instead of 9 times.
 // A K-step = 2 taps x 32 channels (the same 32 MFMAs per wave and barrier as above); the weights of the step come as
 // [2 taps][BN rows][64 B].  LDS-DMA wave-instructions per wave and step: 4 (weights) + 1.25 (patch) instead of 8; gathered
 // bytes per step 4.9 KiB instead of 16 KiB.  64-byte pixels: the 16-byte chunk index is XOR-ed with ((pixel >> 2) & 1) << 1
@@ -496,16 +498,17 @@ __global__ __launch_bounds__(256, 2) void igemm_patch_kernel(KParams p) {
   typedef uint16_t T;
   constexpr int BM = 128, NWN = 2, NTHR = 256, TH = 8, TW = 16;
   constexpr int WN = BN / NWN, NT = WN / 16, MT = 4;
-  constexpr bool S2 = GEOM == ADN_GEMM_S2;
-  constexpr int MW = TW + 1;                                  // patch columns per plane
-  constexpr int SEG_PIX = S2 ? 2 * (TH + 1) * MW : (TH + 1) * MW;   // pixels of one patch segment (306 / 153)
-  constexpr int SEG_STEPS = S2 ? 4 : 2;                       // K-steps served by one segment
-  constexpr int PPIECES = (SEG_PIX + 15) / 16;                // 1-KiB DMA pieces per segment (20 / 10)
-  constexpr int PK = (PPIECES + 3) / 4;                       // pieces per wave (5 / 3)
+  constexpr bool S2 = GEOM == ADN_GEMM_S2, S1 = GEOM == ADN_GEMM_S1;
+  constexpr int MW = S1 ? TW + 2 : TW + 1;                    // patch columns per plane (S1: 3 x 3 window, 18 columns)
+  constexpr int SEG_PIX = S2 ? 2 * (TH + 1) * MW : (S1 ? (TH + 2) * MW : (TH + 1) * MW);   // 306 / 180 / 153 pixels
+  constexpr int SEG_STEPS = S2 ? 4 : (S1 ? 3 : 2);            // K-steps served by one segment
+  constexpr int TPS = S1 ? 3 : 2;                             // taps per K-step (S1: one kernel row)
+  constexpr int PPIECES = (SEG_PIX + 15) / 16;                // 1-KiB DMA pieces per segment (20 / 12 / 10)
+  constexpr int PK = (PPIECES + 3) / 4;                       // pieces per wave (5 / 3 / 3)
   constexpr int PBUF = PPIECES * 1024;
   constexpr int BPT = BN / 16;                                // weight pieces per tap
-  constexpr int BK_ = 2 * BPT / 4;                            // weight pieces per wave and step (4 / 2)
-  constexpr int BBUF = 2 * BN * 64;                           // one weight stage: [2 taps][BN][64 B]
+  constexpr int BK_ = TPS * BPT / 4;                          // weight pieces per wave and step (4 / 2, S1: 6 / 3)
+  constexpr int BBUF = TPS * BN * 64;                         // one weight stage: [TPS taps][BN][64 B]
   constexpr int LDC = BN + 4;
   constexpr unsigned OOB = 0x80000000u;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -515,7 +518,7 @@ __global__ __launch_bounds__(256, 2) void igemm_patch_kernel(KParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  constexpr int NPH = S2 ? 1 : 4;
+  constexpr int NPH = (S2 || S1) ? 1 : 4;
   const int nwg = p.tiles_m * p.tiles_n * NPH;
   const int wg0 = xcd_remap(blockIdx.x, nwg);
   const int phase = wg0 % NPH;
@@ -530,8 +533,8 @@ __global__ __launch_bounds__(256, 2) void igemm_patch_kernel(KParams p) {
   const int tb = tile_m / tpi, trem = tile_m - tb * tpi;
   const int oy0 = (trem / tpr) * TH, ox0 = (trem % tpr) * TW;
   // gathered image: S2 gathers from the large grid (2Hs x 2Ws), T2 from the small grid
-  const int Hg = S2 ? Hl : Hs, Wg = S2 ? Wl : Ws;
-  const int ymin = S2 ? 0 : (ph == 0 ? -1 : 0), xmin = S2 ? 0 : (pw == 0 ? -1 : 0);
+  const int Hg = S2 ? Hl : Hs, Wg = S2 ? Wl : Ws;        // (S1 and T2 gather from the small grid)
+  const int ymin = (S2 || S1) ? 0 : (ph == 0 ? -1 : 0), xmin = (S2 || S1) ? 0 : (pw == 0 ? -1 : 0);
 
   // ---- patch loader geometry (per lane, constant over the K loop) ----
   // piece pi = wave + 4k covers LDS pixels q = 16 pi .. 16 pi + 15; lane l -> pixel 16 pi + (l >> 2), physical chunk l & 3
@@ -553,8 +556,8 @@ __global__ __launch_bounds__(256, 2) void igemm_patch_kernel(KParams p) {
       ok1 = okx && (unsigned)(iy + 1) < (unsigned)Hg;
     } else {
       const int hr = q / MW, m = q - hr * MW;
-      iy = oy0 + hr + ymin;
-      ix = ox0 + m + xmin;
+      iy = oy0 + hr + (S1 ? -1 : ymin);
+      ix = ox0 + m + (S1 ? -1 : xmin);
       ok0 = ok1 = (unsigned)ix < (unsigned)Wg && (unsigned)iy < (unsigned)Hg && q < SEG_PIX;
     }
     ppix[k] = (unsigned)((tb * Hg + iy) * Wg + ix + bshift);
@@ -576,7 +579,8 @@ __global__ __launch_bounds__(256, 2) void igemm_patch_kernel(KParams p) {
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(reinterpret_cast<const char*>(p.C1 ? p.in1 : p.in0) - (int64_t)bshift * p.C1 * 2), 0, p.rec_a, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(reinterpret_cast<const char*>(p.w) + (S2 ? 0 : (int64_t)phase * p.N * ktot * 2)), 0, p.rec_b, 0x00020000);
+      (void*)(reinterpret_cast<const char*>(p.w) + ((S2 || S1) ? 0 : (int64_t)phase * p.N * ktot * 2)), 0, p.rec_b,
+      0x00020000);
 
   const int nchunks = Cin >> 5;
   const int nseg = S2 ? 2 * nchunks : nchunks;
@@ -614,7 +618,7 @@ __global__ __launch_bounds__(256, 2) void igemm_patch_kernel(KParams p) {
       t0 = ky * 4 + 2 * (ss & 1);
     } else {
       c = sg;
-      t0 = 2 * ss;
+      t0 = TPS * ss;
     }
     const int soff = (t0 * Cin + (c << 5)) * 2;
     char* dst = Bl + (s & 1) * BBUF + wave * 1024;
@@ -634,12 +638,13 @@ __global__ __launch_bounds__(256, 2) void igemm_patch_kernel(KParams p) {
   const int e_n0 = tile_n * BN + e_cg * 8;
   auto row_op = [&](int row) -> int64_t {       // output pixel index of tile row `row` (row = oyl * 16 + oxl)
     const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
-    if constexpr (S2) return ((int64_t)tb * Hs + oy) * Ws + ox;
+    if constexpr (S2 || S1) return ((int64_t)tb * Hs + oy) * Ws + ox;
     else return ((int64_t)tb * Hl + 2 * oy + ph) * Wl + 2 * ox + pw;
   };
   // (S2 = dgrad of a transposed conv never accumulates in the U-Net: its running-gradient chunk is not kept in registers
   //  -- 32 VGPRs that made the 128-column variant spill -- but read in the epilogue if a caller asks for it)
-  constexpr int NPO = S2 ? 1 : RPT;
+  constexpr bool KEEP_OLD = !(S2 || S1);      // T2 (dgrad of the strided conv) is the accumulating one in the U-Net
+  constexpr int NPO = KEEP_OLD ? RPT : 1;
   const bool pre_on = p.epi == ADN_EPI_BWD;
   u32x4_t pre_r[RPT], pre_o[NPO], pre_z[RPT];
   if (pre_on) {
@@ -651,7 +656,7 @@ __global__ __launch_bounds__(256, 2) void igemm_patch_kernel(KParams p) {
       const int64_t idx = row_op(e_rsub + RSTEP * k) * sq.channels + nl0;
       pre_r[k] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const uint16_t*>(sq.ref) + idx);
       pre_z[k] = u32x4_t{0u, 0u, 0u, 0u};
-      if constexpr (!S2) {
+      if constexpr (KEEP_OLD) {
         pre_o[k] = u32x4_t{0u, 0u, 0u, 0u};
         if (sq.accumulate) pre_o[k] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const uint16_t*>(sq.out0) + idx);
       }
@@ -680,9 +685,10 @@ __global__ __launch_bounds__(256, 2) void igemm_patch_kernel(KParams p) {
       if (sg + 1 < nseg) issue_patch(sg + 1, ss);
       const char* Bb = Bl + (s & 1) * BBUF;
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {                 // the step's two taps, 32 channels each
+      for (int e = 0; e < TPS; ++e) {               // the step's taps, 32 channels each
         int qoff;
         if constexpr (S2) qoff = ((e * (TH + 1)) + (ss >> 1)) * MW + (ss & 1);     // kx = 2 (ss & 1) + e, ky >> 1 = ss >> 1
+        else if constexpr (S1) qoff = ss * MW + e;                                  // (ky, kx) = (ss, e)
         else qoff = (adn_t2_dy(ph, ss) - ymin) * MW + (adn_t2_dy(pw, e) - xmin);
         u32x4_t af[MT], bf[NT];
 #pragma unroll
@@ -743,7 +749,7 @@ __global__ __launch_bounds__(256, 2) void igemm_patch_kernel(KParams p) {
       v[4 + e] = v1[e];
     }
     if (pre_on) {
-      if constexpr (S2) {
+      if constexpr (!KEEP_OLD) {
         u32x4_t old = {0u, 0u, 0u, 0u};
         if (sg2.accumulate) old = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const uint16_t*>(sg2.out0) + op * sg2.channels + nl);
         epi_bwd_pre8(sg2, cols, op, nl, v, pre_r[k], old, pre_z[k], s1, s2);
@@ -958,8 +964,8 @@ bool make_plan(const AdnIgemmDesc* d, Plan* pl) {
   pl->nsplit = ns;
   // patch-staged variant: bf16, every chunk of 32 channels inside one source, images tileable by 8 x 16 output pixels,
   // enough tiles that no split-K is wanted (ADN_IGEMM_PATCH=0 switches it off)
-  pl->patch = d->dtype == ADN_BF16 && pl->wide && ns == 1 && d->geom != ADN_GEMM_S1 && d->Hs % 8 == 0 && d->Ws % 16 == 0 &&
-              tn.patch != 0;
+  pl->patch = d->dtype == ADN_BF16 && pl->wide && ns == 1 && (d->geom != ADN_GEMM_S1 || d->ks == 3) && d->Hs % 8 == 0 &&
+              d->Ws % 16 == 0 && tn.patch != 0;
   if (pl->patch) {
     pl->bm = 128;
     pl->tiles_m = (int)(msmall / 128);
@@ -1004,9 +1010,9 @@ void dispatch_mfma(const KParams& kp, const Plan& pl, hipStream_t st) {
 
 template <int BN, int GEOM>
 void launch_patch1(const KParams& kp, const Plan& pl, hipStream_t st) {
-  constexpr bool S2 = GEOM == ADN_GEMM_S2;
-  constexpr int ppieces = ((S2 ? 2 * 9 * 17 : 9 * 17) + 15) / 16;
-  constexpr int stage = 2 * ppieces * 1024 + 2 * 2 * BN * 64;
+  constexpr bool S2 = GEOM == ADN_GEMM_S2, S1 = GEOM == ADN_GEMM_S1;
+  constexpr int ppieces = ((S2 ? 2 * 9 * 17 : (S1 ? 10 * 18 : 9 * 17)) + 15) / 16;
+  constexpr int stage = 2 * ppieces * 1024 + 2 * (S1 ? 3 : 2) * BN * 64;
   constexpr int epil = 128 * (BN + 4) * 4;
   constexpr int lds = stage > epil ? stage : epil;
   ADN_SET_LDS_ONCE(lds, &igemm_patch_kernel<BN, GEOM>);
@@ -1017,9 +1023,12 @@ inline void launch_patch(const KParams& kp, const Plan& pl, int geom, hipStream_
   if (geom == ADN_GEMM_S2) {
     if (pl.bn == 128) launch_patch1<128, ADN_GEMM_S2>(kp, pl, st);
     else launch_patch1<64, ADN_GEMM_S2>(kp, pl, st);
-  } else {
+  } else if (geom == ADN_GEMM_T2) {
     if (pl.bn == 128) launch_patch1<128, ADN_GEMM_T2>(kp, pl, st);
     else launch_patch1<64, ADN_GEMM_T2>(kp, pl, st);
+  } else {
+    if (pl.bn == 128) launch_patch1<128, ADN_GEMM_S1>(kp, pl, st);
+    else launch_patch1<64, ADN_GEMM_S1>(kp, pl, st);
   }
 }
 
