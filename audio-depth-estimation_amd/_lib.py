@@ -174,6 +174,9 @@ _PROTOS = {
     'adn_optimizer_step': (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_float,
                                      c_float, c_float, c_float, c_int32, c_void_p, c_void_p, c_void_p]),
     'adn_pack_t2_multi': (C.c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p]),
+    'adn_edge_loss_workspace_bytes': (c_int64, [c_int32, c_int32, c_int32]),
+    'adn_edge_loss': (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_float, c_float, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_int64, c_void_p]),
     'adn_compute_errors': (C.c_int, [c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
     'adn_compute_errors_workspace_bytes': (c_int64, [c_int32, c_int64]),
     'adn_frontend_workspace_bytes': (c_int64, [c_int32, c_int32, c_int32]),

@@ -16,6 +16,10 @@ reduce_add per step) with replicated weights and ONE exch
 Bucket size: xGMI is point-to-point (7 links x ~153 GB/s per GPU) so collectives are per-link
 bound; 217.6 MB of U-Net gradients go out as a few large (default 32 MiB) buckets rather than 43
 per-tensor messages.  Works with the gloo backend on CPU tensors too (tests, world_size 2).
+Optional ``payload='bf16'``: every bucket is cast to bf16 before the exchange and back afterwards (108.8 MB instead of
+217.6 MB on the links for the U-Net; SURVEY section 5: the exchange time decides the 8-GPU scaling target).  The SUM then
+runs in bf16 -- about 3 significant digits per element, the order of the bf16 compute path's own gradient error; the
+default stays f32, which is what the parity tests (bit-identical replicas vs a single-process emulation) pin.
 """
 from __future__ import annotations
 
@@ -24,10 +28,14 @@ import torch.distributed as dist
 
 
 class GradientAllReducer:
-    def __init__(self, process_group=None, bucket_bytes: int = 32 << 20):
+    def __init__(self, process_group=None, bucket_bytes: int = 32 << 20, payload: str = 'f32'):
         if not dist.is_available() or not dist.is_initialized():
             raise RuntimeError('GradientAllReducer needs an initialised torch.distributed process group')
+        if payload not in ('f32', 'bf16'):
+            raise ValueError(f"payload must be 'f32' or 'bf16', got {payload!r}")
         self.pg = process_group
+        self.payload = payload
+        self.g16 = None            # bf16 staging buffer of the exchange (payload='bf16')
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.buckets = []          # (lo, hi) element ranges, ordered from the end of the buffer
         self.flat_g = None
@@ -51,6 +59,7 @@ class GradientAllReducer:
         engine.on_grad_ready = self.on_grad_ready
         self._next = 0
         self._works = []
+        self.g16 = torch.empty(n, dtype=torch.bfloat16, device=self.flat_g.device) if self.payload == 'bf16' else None
 
     def broadcast_parameters(self, flat_p, src=0):
         """Replicate rank ``src``'s weights (what DataParallel.replicate does every forward; once here)."""
@@ -67,15 +76,22 @@ class GradientAllReducer:
         """flat_g[offset_lo:] is final: launch every bucket that lies entirely above the watermark."""
         while self._next < len(self.buckets) and self.buckets[self._next][0] >= offset_lo:
             lo, hi = self.buckets[self._next]
-            self._works.append(dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.pg,
-                                               async_op=True))
+            if self.g16 is not None:
+                # cast on the compute stream (ordered behind the kernels that produced the bucket), exchange bf16
+                self.g16[lo:hi].copy_(self.flat_g[lo:hi])
+                buf = self.g16[lo:hi]
+            else:
+                buf = self.flat_g[lo:hi]
+            self._works.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), lo, hi))
             self._next += 1
 
     def finish(self):
         """Flush the remaining buckets and make the compute stream wait for all collectives."""
         self.on_grad_ready(0)
-        for w in self._works:
-            w.wait()
+        for w, lo, hi in self._works:
+            w.wait()                              # the compute stream now waits for the collective's stream
+            if self.g16 is not None:
+                self.flat_g[lo:hi].copy_(self.g16[lo:hi])
         self._works = []
 
 

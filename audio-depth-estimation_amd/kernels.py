@@ -359,6 +359,18 @@ def pack_t2_multi(flat_master, table, layers, total_blocks, dtype, t2_base):
               dtype_code(dtype), ptr(t2_base), _stream())
 
 
+def edge_loss(pred, gt, lambdas, stats, terms, grad, workspace):
+    """Edge-aware / smoothness loss (adn_edge_loss): pred, gt f32 [B,1,H,W]; lambdas = (recon, edge, smooth)."""
+    _dev(pred, gt, stats, terms, grad, workspace)
+    B, H, W = pred.shape[0], pred.shape[-2], pred.shape[-1]
+    _lib.call('adn_edge_loss', ptr(pred), ptr(gt), B, H, W, float(lambdas[0]), float(lambdas[1]), float(lambdas[2]),
+              ptr(stats), ptr(terms), ptr(grad), ptr(workspace), workspace.numel() * workspace.element_size(), _stream())
+
+
+def edge_loss_workspace_bytes(B, H, W):
+    return _lib.load().adn_edge_loss_workspace_bytes(B, H, W)
+
+
 def compute_errors(gt, pred, out7):
     """gt/pred [samples, pixels] f32 -> out7 [samples, 7]."""
     _dev(gt, pred, out7)

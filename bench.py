@@ -273,7 +273,8 @@ def main():
         for name in ('r02_pmc_traffic_gemm.json', 'r01_pmc_traffic_gemm.json'):
             try:
                 pm = json.load(open(os.path.join(ROOT, 'profiles', name)))
-                rows = [v for k, v in pm.items() if k.startswith(dom)]
+                fams = ('igemm_patch_kernel', 'igemm_mfma_kernel') if dom == 'igemm' else ('wgrad_mfma_kernel',)
+                rows = [v for k, v in pm.items() if k.startswith(fams)]
                 if rows and args.dtype == 'bf16' and B == 32:
                     traffic = sum(r['launches'] * r['hbm_bytes_per_launch'] for r in rows) / sum(r['launches'] for r in rows)
                     traffic_src = 'profiles/' + name
@@ -292,7 +293,9 @@ def main():
                                    f'batch {B}/GPU, Combined L1+SIlog loss, clip 1.0, AdamW',
                        'global_batch': world * B, 'image_size': S, 'launch': 'hipGraph' if use_graph else 'launch-plan',
                        'parallelism': par},
-            'roofline': {'bound': 'mfma', 'kernel': {'igemm': 'igemm_mfma_kernel', 'wgrad': 'wgrad_mfma_kernel'}.get(dom, dom),
+            'roofline': {'bound': 'mfma',
+                         'kernel': {'igemm': 'igemm_patch_kernel + igemm_mfma_kernel (implicit-GEMM family: forward + input gradients)',
+                                    'wgrad': 'wgrad_mfma_kernel'}.get(dom, dom),
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
                          'traffic': traffic, 'traffic_source': traffic_src, 'launches': launches,
                          'avg_launch_ms': 1e3 * secs / launches,

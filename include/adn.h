@@ -441,6 +441,16 @@ int adn_optimizer_step(float* params, const float* grads, float* exp_avg, float*
 int adn_pack_t2_multi(const void* flat_master, int32_t master_dtype, const int64_t* table, int32_t layers,
                       int64_t total_blocks, int32_t dtype, void* t2_base, void* stream);
 
+/* Edge-aware / smoothness loss of the binaural family (utils_binaural_attention_loss.py:15-156) on single-channel f32
+ * maps [B][H][W]: lambda_recon * L1 over valid (gt > 0) + lambda_edge * |Sobel magnitude(pred) - Sobel magnitude(gt)|
+ * over the 3x3-dilated valid mask + lambda_smooth * (|Sx pred| + |Sy pred|) * exp(-Sobel magnitude(gt)) over valid.
+ * stats (5 doubles: n valid, sum |e|, n dilated, sum edge, sum smooth), terms (4 floats: recon, edge, smooth, total),
+ * grad (optional, f32 [B][H][W]): d total / d pred. */
+int64_t adn_edge_loss_workspace_bytes(int32_t B, int32_t H, int32_t W);
+int adn_edge_loss(const float* pred, const float* gt, int32_t B, int32_t H, int32_t W, float lambda_recon,
+                  float lambda_edge, float lambda_smooth, double* stats, float* terms, float* grad,
+                  void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Evaluation metrics (compute_errors, utils_criterion.py:6-90), one set of 7 floats per sample:
  * (abs_rel, rmse, a1, a2, a3, log_10, mae). gt/pred: [samples][pixels] f32. */
 int adn_compute_errors(const float* gt, const float* pred, int32_t samples, int64_t pixels,

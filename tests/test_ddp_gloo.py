@@ -99,6 +99,22 @@ def _worker(rank, world, port, out):
         assert torch.equal(full[off:], torch.arange(off, n, dtype=torch.float32) * tot)
         assert torch.equal(full[:off], torch.arange(off, dtype=torch.float32) * (rank + 1))      # untouched prefix
 
+        # ---- 1c. bf16 payload: the exchange runs on a bf16 copy of every bucket, the f32 buffer receives the sum back
+        eng3 = _FakeEngine(1000)
+        red3 = GradientAllReducer(bucket_bytes=4 * 300, payload='bf16')
+        red3.attach(eng3)
+        g3 = torch.Generator().manual_seed(5 + rank)
+        eng3.flat_g.copy_(torch.randn(1000, generator=g3))
+        mine = eng3.flat_g.clone()
+        others = [torch.randn(1000, generator=torch.Generator().manual_seed(5 + r)) for r in range(world)]
+        red3.begin_backward()
+        eng3.on_grad_ready(0)
+        red3.finish()
+        assert torch.equal(mine, others[rank])
+        want = sum(o.to(torch.bfloat16).float() for o in others)         # bf16 operands, summed (gloo sums in bf16 too)
+        assert float((eng3.flat_g - want).abs().max()) <= 2 ** -7 * float(want.abs().max())
+        assert eng3.flat_g.dtype == torch.float32 and red3.g16.dtype == torch.bfloat16
+
         # ---- 2. data-parallel step with the oracle
         sd = _model_sd()
         pkeys = unet_oracle.param_keys(7)

@@ -100,7 +100,10 @@ def test_train_then_test_entrypoints_synthetic(tmp_path, monkeypatch):
     exp = 'unet_256_batvisionv2_BS4_Lr0.002_AdamW_smoke'
     ck = torch.load(tmp_path / 'checkpoints' / exp / 'checkpoint_10.pth', map_location='cpu')
     assert set(ck) == {'epoch', 'state_dict', 'optimizer'} and ck['epoch'] == 10 and len(ck['state_dict']) == 82
-    assert ck['optimizer']['step'] == 20
+    opt_sd = ck['optimizer']                                # torch.optim format, what the reference's optimizer writes
+    assert float(opt_sd['state'][0]['step']) == 20 and len(opt_sd['param_groups'][0]['params']) == 43
+    probe = torch.optim.AdamW([torch.nn.Parameter(torch.zeros_like(p, device='cpu')) for p in model.parameters()], lr=0.002)
+    probe.load_state_dict(opt_sd)                           # a real torch optimizer accepts it
     assert (tmp_path / 'checkpoints' / exp / 'best_model.pth').exists()
     mean = adn_test.main(['--synthetic', '4', '--experiment_name', exp, '--checkpoints', '10', '--batch_size', '2'])
     assert len(mean) == 7 and all(np.isfinite(mean))

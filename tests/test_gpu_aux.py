@@ -197,3 +197,32 @@ def test_dc_trainer_entry_points_synthetic(which, tmp_path, monkeypatch):
         train_dc.main_rgb(common[:4] + ['--nb_epochs', '3', '--experiment_name', 'smoke', '--save_frequency', '1',
                                         '--checkpoints', '2'])
         assert os.path.exists(os.path.join('checkpoints', 'smoke', 'epoch_0003.pth'))
+
+
+def test_edge_aware_loss_matches_reference_golden():
+    """utils_binaural_attention_loss mirror (adn_edge_loss): the three terms, the total and d total / d pred against the
+    fixture generated from the reference's BinauralAttentionLoss; the epoch curriculum of the adaptive variant."""
+    from audio_depth_estimation_amd.utils_binaural_attention_loss import AdaptiveBinauralAttentionLoss, BinauralAttentionLoss
+    z = np.load(os.path.join(GOLDEN, 'edge_loss_cases.npz'))
+    for name in ('random', 'box', 'all_invalid'):
+        for tag in ('default', 'heavy'):
+            k = f'{name}/{tag}/'
+            crit = BinauralAttentionLoss(*[float(v) for v in z[k + 'lambdas']])
+            assert sorted(crit.state_dict().keys()) == ['sobel_x', 'sobel_y']
+            pred = torch.from_numpy(z[name + '/pred']).to(DEV).requires_grad_(True)
+            gt = torch.from_numpy(z[name + '/gt']).to(DEV)
+            total, d = crit(pred, gt)
+            got = np.array([d['loss_recon'], d['loss_edge'], d['loss_smooth'], d['loss_total']])
+            np.testing.assert_allclose(got, z[k + 'terms'], rtol=5e-5, atol=1e-6)
+            assert abs(float(total) - float(z[k + 'terms'][3])) <= 5e-5 * abs(float(z[k + 'terms'][3])) + 1e-6
+            (2.0 * total).backward()                                   # upstream factor reaches the input gradient
+            ref = 2.0 * z[k + 'grad']
+            assert float(np.abs(pred.grad.cpu().numpy() - ref).max()) <= 1e-4 * float(np.abs(ref).max()) + 1e-8
+    ad = AdaptiveBinauralAttentionLoss(warmup_epochs=20, total_epochs=200)
+    pred, gt = torch.from_numpy(z['random/pred']).to(DEV), torch.from_numpy(z['random/gt']).to(DEV)
+    for epoch, lr, le, ls, tot in z['adaptive']:
+        _, d = ad(pred, gt, int(epoch))
+        np.testing.assert_allclose([d['lambda_recon'], d['lambda_edge'], d['lambda_smooth']], [lr, le, ls], rtol=1e-6, atol=1e-9)
+        assert abs(d['loss_total'] - tot) <= 5e-5 * abs(tot) + 1e-6
+    with pytest.raises(RuntimeError):
+        BinauralAttentionLoss()(torch.zeros(1, 1, 8, 8), torch.zeros(1, 1, 8, 8))

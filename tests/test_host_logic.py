@@ -57,3 +57,56 @@ def test_cpu_model_call_raises():
     m = define_G(SimpleNamespace(dataset=SimpleNamespace(depth_norm=False)), 2, 1, 4, 'unet_128')
     with pytest.raises(RuntimeError, match='HIP'):
         m(torch.rand(1, 2, 128, 128))
+
+
+def test_optimizer_state_is_torch_optim_format_and_round_trips():
+    """optim_state.export_state writes what torch.optim.AdamW.state_dict() holds (so the reference's
+    optimizer.load_state_dict reads it, train_binaural_attention.py:361) and import_state reads a state written by a
+    REAL torch optimizer over the same parameters back into the flat, channels_last moment buffers."""
+    import torch
+    from audio_depth_estimation_amd import optim_state
+    from audio_depth_estimation_amd.flat import FlatParamEngine
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.randn(6, 4, 4, 4)), torch.nn.Parameter(torch.randn(6)),
+              torch.nn.Parameter(torch.randn(5, 6, 3, 3))]
+    # a real torch optimizer takes two steps
+    opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=0.01)
+    for _ in range(2):
+        for p in params:
+            p.grad = torch.randn_like(p)
+        opt.step()
+    ref = opt.state_dict()
+    # flat layout of flat.py: parameters() order, conv tensors in channels_last memory
+    meta, total = [], 0
+    for p in params:
+        meta.append((p, total, p.numel()))
+        total += (p.numel() + 7) // 8 * 8
+    m, v = torch.zeros(total), torch.zeros(total)
+    step, group = optim_state.import_state(ref, meta, FlatParamEngine._view, m, v)
+    assert step == 2 and group['lr'] == 1e-3
+    for i, (p, off, n) in enumerate(meta):
+        assert torch.equal(FlatParamEngine._view(m, off, p), ref['state'][i]['exp_avg'])
+        if p.dim() == 4:          # memory order of the flat slice is [X][kh][kw][Y]
+            assert torch.equal(m[off:off + n].view(p.shape[0], p.shape[2], p.shape[3], p.shape[1]),
+                               ref['state'][i]['exp_avg'].permute(0, 2, 3, 1))
+    out = optim_state.export_state(meta, FlatParamEngine._view, m, v, step, 0, 1e-3, (0.9, 0.999), 1e-8, 0.01)
+    assert optim_state.is_torch_format(out)
+    assert set(out['param_groups'][0].keys()) == set(ref['param_groups'][0].keys())
+    for i in range(len(params)):
+        assert float(out['state'][i]['step']) == 2.0
+        assert torch.equal(out['state'][i]['exp_avg'], ref['state'][i]['exp_avg'])
+        assert torch.equal(out['state'][i]['exp_avg_sq'], ref['state'][i]['exp_avg_sq'])
+    # ... and a fresh torch optimizer accepts it and continues exactly like the original
+    opt2 = torch.optim.AdamW([torch.nn.Parameter(p.detach().clone()) for p in params], lr=1e-3, weight_decay=0.01)
+    opt2.load_state_dict(out)
+    gs = [torch.randn_like(p) for p in params]
+    for p, q, g in zip(params, opt2.param_groups[0]['params'], gs):
+        p.grad, q.grad = g.clone(), g.clone()
+    opt.step()
+    opt2.step()
+    for p, q in zip(params, opt2.param_groups[0]['params']):
+        assert torch.equal(p.detach(), q.detach())
+    # a parameter list of another length is refused
+    import pytest
+    with pytest.raises(ValueError):
+        optim_state.import_state(ref, meta[:2], FlatParamEngine._view, m, v)

@@ -321,3 +321,21 @@ def test_base_residual_oracle_matches_reference():
             gr, ref = sdg[kk].grad, z[f'{tag}/gs/' + kk]
             assert abs(float(gr.double().norm()) - float(z[f'{tag}/gnorm/' + kk])) <= 5e-3 * float(z[f'{tag}/gnorm/' + kk]) + 1e-7, kk
             np.testing.assert_allclose(_sample(gr), ref, rtol=5e-3, atol=1e-6 + 5e-3 * np.abs(ref).max(), err_msg=kk)
+
+
+def test_edge_loss_oracle_matches_reference_golden():
+    """oracle/edge_loss_oracle.py against the reference's BinauralAttentionLoss (values + autograd gradients)."""
+    from oracle import edge_loss_oracle as E
+    z = np.load(os.path.join(GOLDEN, 'edge_loss_cases.npz'))
+    for name in ('random', 'box', 'all_invalid'):
+        for tag in ('default', 'heavy'):
+            k = f'{name}/{tag}/'
+            pred = torch.from_numpy(z[name + '/pred']).double().requires_grad_(True)
+            gt = torch.from_numpy(z[name + '/gt']).double()
+            total, (r, e, s) = E.edge_loss(pred, gt, *[float(v) for v in z[k + 'lambdas']])
+            got = np.array([float(r), float(e), float(s), float(total)])
+            np.testing.assert_allclose(got, z[k + 'terms'], rtol=2e-5, atol=1e-7)
+            if total.requires_grad and name != 'all_invalid':
+                total.backward()
+                ref = z[k + 'grad']
+                assert float(np.abs(pred.grad.numpy() - ref).max()) <= 2e-5 * float(np.abs(ref).max()) + 1e-9
