@@ -1,6 +1,8 @@
-// Audio front-end on device: centred reflect-padded STFT magnitude (n_fft 512, periodic Hann(64),
-// hop 16 or 32) as a 64-tap windowed DFT, optional HTK mel projection (257 -> 32), log + per-channel
-// min-max, bilinear resize (align_corners=False, optional antialias) to S x S.
+// Audio front-end on device: centred reflect-padded STFT magnitude as a WIN-tap windowed DFT (periodic Hann), optional
+// HTK mel projection (-> 32), log + per-channel min-max, bilinear resize (align_corners=False, optional antialias) to
+// S x S.  Two STFT configurations, as in the reference (BatvisionV2_Dataset.py:96-109): the cut one (audio cut to
+// 2*max_depth/340 s: n_fft 512, win 64, hop 16, mel hop 32) and the un-cut one (dataset.max_depth unset: n_fft 400,
+// win 200, hop 100 for both formats).
 // Follows SURVEY.md Appendix B; reference call sites: dataloader/BatvisionV2_Dataset.py:94-135,
 // :177-197, dataloader/BatvisionV1_Dataset.py:68-95, dataloader/utils_dataset.py:18-20.
 //
@@ -10,14 +12,16 @@
 
 namespace {
 
-constexpr int NFFT = 512, WIN = 64, NBIN = 257, NMEL = 32, PAD = 256, OFF = 224;
+constexpr int NMEL = 32;
 constexpr int FT = 8;  // frames per block
 
+template <int NFFT, int WIN>
 __global__ __launch_bounds__(256) void fe_tables_kernel(float* bcos, float* bsin, float* fb) {
+  constexpr int NBIN = NFFT / 2 + 1, OFF = (NFFT - WIN) / 2;
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx < NBIN * WIN) {
     const int k = idx / WIN, j = idx % WIN;
-    const int ph = (k * (OFF + j)) & (NFFT - 1);                  // exact integer phase reduction
+    const int ph = (k * (OFF + j)) % NFFT;                        // exact integer phase reduction
     const double w = 0.5 - 0.5 * cospi(2.0 * (double)j / WIN);    // periodic Hann
     bcos[idx] = (float)(w * cospi(2.0 * ph / (double)NFFT));
     bsin[idx] = (float)(-w * sinpi(2.0 * ph / (double)NFFT));
@@ -39,9 +43,11 @@ __global__ __launch_bounds__(256) void fe_tables_kernel(float* bcos, float* bsin
 __device__ __forceinline__ int reflect(int i, int T) { return i < 0 ? -i : (i >= T ? 2 * (T - 1) - i : i); }
 
 // grid (frame tiles, B*2).  mode 0: mel+log, 1: linear+log, 2: linear raw.
+template <int NFFT, int WIN>
 __global__ __launch_bounds__(256) void fe_stft_kernel(const float* wave, int T, int hop, int nT, int mode,
                                                       const float* bcos, const float* bsin, const float* fb,
                                                       float* spec, float* mm_part, int tiles) {
+  constexpr int NBIN = NFFT / 2 + 1, PAD = NFFT / 2, OFF = (NFFT - WIN) / 2;
   __shared__ float fr[FT][WIN];
   __shared__ float mag[FT][NBIN + 3];
   __shared__ float red[8];
@@ -185,14 +191,22 @@ __global__ __launch_bounds__(256) void fe_resize_kernel(const float* spec, const
 }
 
 struct FeDims {
-  int hop, nT, F, tiles;
+  int hop, nT, F, tiles, nfft, win, nbin, kmode;
   int64_t off_cos, off_sin, off_fb, off_spec, off_mm, total;
 };
+// mode 0 / 1 / 2: cut configuration (mel+log, linear+log, linear raw); 3 / 4: un-cut configuration (mel+log, linear+log)
 FeDims fe_dims(int B, int T, int mode) {
   FeDims d;
-  d.hop = mode == 0 ? WIN / 2 : WIN / 4;      // mel path passes no hop_length -> win_length//2
+  const bool uncut = mode >= 3;
+  d.nfft = uncut ? 400 : 512;
+  d.win = uncut ? 200 : 64;
+  d.nbin = d.nfft / 2 + 1;
+  d.kmode = uncut ? mode - 3 : mode;            // what the kernels see: 0 mel+log, 1 linear+log, 2 linear raw
+  const int NBIN = d.nbin, WIN = d.win;
+  // mel path passes no hop_length -> win_length // 2 (= 32 cut, 100 un-cut); linear: 16 cut (:108), 100 un-cut (:99)
+  d.hop = uncut ? 100 : (mode == 0 ? WIN / 2 : WIN / 4);
   d.nT = 1 + T / d.hop;
-  d.F = mode == 0 ? NMEL : NBIN;
+  d.F = d.kmode == 0 ? NMEL : NBIN;
   d.tiles = (int)adn_cdiv(d.nT, FT);
   d.off_cos = 0;
   d.off_sin = d.off_cos + NBIN * WIN;
@@ -206,27 +220,34 @@ FeDims fe_dims(int B, int T, int mode) {
 }  // namespace
 
 extern "C" int64_t adn_frontend_workspace_bytes(int32_t B, int32_t T, int32_t mode) {
-  if (B <= 0 || T <= 0 || mode < 0 || mode > 2) return -1;
+  if (B <= 0 || T <= 0 || mode < 0 || mode > 4) return -1;
   return fe_dims(B, T, mode).total * 4;
 }
 
 extern "C" int adn_frontend(const float* wave, int32_t B, int32_t T, int32_t mode, int32_t S, int32_t antialias,
                             float* out, void* workspace, int64_t workspace_bytes, void* stream) {
   ADN_CHECK_ARG(wave && out && workspace && B > 0 && S > 0, "adn_frontend: bad arguments");
-  ADN_CHECK_ARG(mode >= 0 && mode <= 2, "adn_frontend: bad mode %d", mode);
-  ADN_CHECK_ARG(T > PAD, "adn_frontend: reflect padding needs T > %d samples (got %d)", PAD, T);
+  ADN_CHECK_ARG(mode >= 0 && mode <= 4, "adn_frontend: bad mode %d", mode);
   const FeDims d = fe_dims(B, T, mode);
+  ADN_CHECK_ARG(T > d.nfft / 2, "adn_frontend: reflect padding needs T > %d samples (got %d)", d.nfft / 2, T);
   ADN_CHECK_ARG(workspace_bytes >= d.total * 4, "adn_frontend: workspace too small");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   float* ws = reinterpret_cast<float*>(workspace);
-  hipLaunchKernelGGL(fe_tables_kernel, dim3((unsigned)adn_cdiv(NBIN * WIN, 256)), dim3(256), 0, st, ws + d.off_cos,
-                     ws + d.off_sin, ws + d.off_fb);
-  ADN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(fe_stft_kernel, dim3(d.tiles, B * 2), dim3(256), 0, st, wave, T, d.hop, d.nT, mode,
-                     ws + d.off_cos, ws + d.off_sin, ws + d.off_fb, ws + d.off_spec, ws + d.off_mm, d.tiles);
+  const dim3 tgrid((unsigned)adn_cdiv(d.nbin * (d.win > NMEL ? d.win : NMEL), 256)), sgrid(d.tiles, B * 2);
+  if (d.nfft == 512) {
+    hipLaunchKernelGGL((fe_tables_kernel<512, 64>), tgrid, dim3(256), 0, st, ws + d.off_cos, ws + d.off_sin, ws + d.off_fb);
+    ADN_CHECK_LAUNCH();
+    hipLaunchKernelGGL((fe_stft_kernel<512, 64>), sgrid, dim3(256), 0, st, wave, T, d.hop, d.nT, d.kmode, ws + d.off_cos,
+                       ws + d.off_sin, ws + d.off_fb, ws + d.off_spec, ws + d.off_mm, d.tiles);
+  } else {
+    hipLaunchKernelGGL((fe_tables_kernel<400, 200>), tgrid, dim3(256), 0, st, ws + d.off_cos, ws + d.off_sin, ws + d.off_fb);
+    ADN_CHECK_LAUNCH();
+    hipLaunchKernelGGL((fe_stft_kernel<400, 200>), sgrid, dim3(256), 0, st, wave, T, d.hop, d.nT, d.kmode, ws + d.off_cos,
+                       ws + d.off_sin, ws + d.off_fb, ws + d.off_spec, ws + d.off_mm, d.tiles);
+  }
   ADN_CHECK_LAUNCH();
   hipLaunchKernelGGL(fe_resize_kernel, dim3((unsigned)adn_cdiv((int64_t)S * S, 256), B * 2), dim3(256), 0, st,
-                     ws + d.off_spec, ws + d.off_mm, d.tiles, d.F, d.nT, S, antialias, mode != 2 ? 1 : 0, out);
+                     ws + d.off_spec, ws + d.off_mm, d.tiles, d.F, d.nT, S, antialias, d.kmode != 2 ? 1 : 0, out);
   ADN_CHECK_LAUNCH();
   return ADN_OK;
 }

@@ -82,16 +82,11 @@ class BatvisionV2Dataset(Dataset):
         waveform, sr = load_wav(os.path.join(self.root_dir, instance['audio path'], instance['audio file name']))
         if self.cfg.dataset.max_depth:
             waveform = waveform[:, :int((2 * self.cfg.dataset.max_depth / 340) * sr)]
-        elif 'waveform' not in self.audio_format:
-            # reference :96-99: without the cut the STFT runs with win 200 / n_fft 400 / hop 100; libadn's front-end is
-            # built for the cut configuration (win 64 / n_fft 512) only -- refuse instead of silently using other parameters
-            raise NotImplementedError('dataset.max_depth is unset: the un-cut spectrogram configuration (win_length 200, '
-                                      'n_fft 400, hop 100; BatvisionV2_Dataset.py:96-99) is not implemented on the libadn '
-                                      'front-end; set dataset.max_depth or use audio_format=waveform')
         if 'waveform' in self.audio_format or self.frontend == 'raw':
             return waveform, gt_depth
         if self._fe is None:
-            mode = 'mel_spectrogram' if 'mel' in self.audio_format else 'spectrogram'
+            # (no max_depth: the un-cut STFT configuration of :96-99)
+            mode = GpuAudioFrontend.bv2_mode(self.audio_format, self.cfg.dataset.max_depth)
             self._fe = GpuAudioFrontend(mode, self.cfg.dataset.images_size, self.antialias)
         if torch.utils.data.get_worker_info() is not None:
             raise RuntimeError("frontend='device' transforms on the HIP device and cannot run inside a DataLoader worker "

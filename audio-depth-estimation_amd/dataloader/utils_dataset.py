@@ -74,9 +74,16 @@ class GpuAudioFrontend:
 
     The MI355X-first data path: DataLoader workers only read files (``frontend='raw'`` datasets), the
     STFT / mel / log / min-max / resize of the whole batch is ONE libadn call (adn_frontend).
-    mode: 'mel_spectrogram' | 'spectrogram' (BV2: log + min-max) | 'bv1' (raw magnitude).
+    mode: 'mel_spectrogram' | 'spectrogram' (BV2: log + min-max) | 'bv1' (raw magnitude); the '_uncut' variants are the
+    BV2 configuration without the max_depth cut (win 200 / n_fft 400 / hop 100, BatvisionV2_Dataset.py:96-99).
     """
-    MODES = {'mel_spectrogram': 0, 'spectrogram': 1, 'bv1': 2}
+    MODES = {'mel_spectrogram': 0, 'spectrogram': 1, 'bv1': 2, 'mel_spectrogram_uncut': 3, 'spectrogram_uncut': 4}
+
+    @classmethod
+    def bv2_mode(cls, audio_format, max_depth):
+        """Mode name for a BV2 audio format and the dataset's max_depth (falsy = no cut)."""
+        base = 'mel_spectrogram' if 'mel' in audio_format else 'spectrogram'
+        return base if max_depth else base + '_uncut'
 
     def __init__(self, mode, size, antialias=True):
         self.mode = self.MODES[mode]

@@ -78,7 +78,7 @@ def main(argv=None):
         from .dataloader.BatvisionV2_Dataset import BatvisionV2Dataset
         ann = cfg.dataset.annotation_file_val if args.eval_on == 'val' else cfg.dataset.annotation_file_test
         eval_set = BatvisionV2Dataset(cfg, ann, frontend='raw')
-        fe = GpuAudioFrontend('mel_spectrogram' if 'mel' in cfg.dataset.audio_format else 'spectrogram', S)
+        fe = GpuAudioFrontend(GpuAudioFrontend.bv2_mode(cfg.dataset.audio_format, cfg.dataset.max_depth), S)
     print(f'Eval Dataset of {len(eval_set)} instances')
     loader = DataLoader(eval_set, batch_size=cfg.mode.batch_size, shuffle=False, num_workers=cfg.mode.num_threads)
 

@@ -135,7 +135,7 @@ def make_loaders(cfg, args, rank, world):
             from .dataloader.BatvisionV2_Dataset import BatvisionV2Dataset
             train = BatvisionV2Dataset(cfg, cfg.dataset.annotation_file_train, use_image=args.eval_img, frontend='raw')
             val = BatvisionV2Dataset(cfg, cfg.dataset.annotation_file_val, use_image=args.eval_img, frontend='raw')
-            mode = 'mel_spectrogram' if 'mel' in cfg.dataset.audio_format else 'spectrogram'
+            mode = GpuAudioFrontend.bv2_mode(cfg.dataset.audio_format, cfg.dataset.max_depth)
             fe = None if args.eval_img else GpuAudioFrontend(mode, cfg.dataset.images_size)
     sampler = torch.utils.data.distributed.DistributedSampler(train, world, rank, shuffle=cfg.mode.shuffle) \
         if world > 1 else None

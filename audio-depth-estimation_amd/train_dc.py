@@ -122,7 +122,7 @@ def _loaders(cfg, args, kind, rank=0, world=1):
             img = kind == 'rgb'
             train = DS(cfg, cfg.dataset.annotation_file_train, use_image=img, frontend='raw')
             val = DS(cfg, cfg.dataset.annotation_file_val, use_image=img, frontend='raw')
-            mode = 'mel_spectrogram' if 'mel' in cfg.dataset.audio_format else 'spectrogram'
+            mode = GpuAudioFrontend.bv2_mode(cfg.dataset.audio_format, cfg.dataset.max_depth)
         if kind == 'audio' and 'waveform' not in cfg.dataset.audio_format:
             fe = GpuAudioFrontend(mode, cfg.dataset.images_size)
         workers = args.num_workers

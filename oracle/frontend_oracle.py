@@ -144,14 +144,19 @@ def resize_bilinear(x: np.ndarray, size: int, antialias: bool = True) -> np.ndar
 
 def bv2_audio_to_input(wave: np.ndarray, max_depth=30.0, images_size=256,
                        audio_format='mel_spectrogram', antialias=True) -> np.ndarray:
-    """Full BV2 audio branch: cut -> (mel)spectrogram -> log -> minmax -> resize."""
-    cut = cut_samples(max_depth)
-    w = wave[:, :cut]
-    if 'mel' in audio_format:
-        spec = stft_mag(w, hop=WIN // 2)                         # hop_length not passed -> win//2 (:187-197)
-        spec = np.einsum('cft,fm->cmt', spec, mel_fbanks())
+    """Full BV2 audio branch: cut -> (mel)spectrogram -> log -> minmax -> resize.  ``max_depth`` falsy = the un-cut
+    configuration of :96-99 (win_length 200, n_fft 400, hop 100; the mel path's default hop win // 2 is 100 too)."""
+    if max_depth:
+        w = wave[:, :cut_samples(max_depth)]
+        n_fft, win, hop_lin = N_FFT, WIN, WIN // 4               # :105-108
     else:
-        spec = stft_mag(w, hop=WIN // 4)                         # hop 16 (:108,:118)
+        w = wave
+        n_fft, win, hop_lin = 400, 200, 100                      # :96-99
+    if 'mel' in audio_format:
+        spec = stft_mag(w, hop=win // 2, n_fft=n_fft, win=win)   # hop_length not passed -> win//2 (:187-197)
+        spec = np.einsum('cft,fm->cmt', spec, mel_fbanks(n_freqs=n_fft // 2 + 1))
+    else:
+        spec = stft_mag(w, hop=hop_lin, n_fft=n_fft, win=win)    # (:108,:118)
     return resize_bilinear(log_minmax(spec), images_size, antialias)
 
 

@@ -86,3 +86,18 @@ def test_log_minmax_branches():
     out = fo.log_minmax(s)
     assert out[0].min() == 0.0 and out[0].max() == 1.0
     assert (out[1] == 0.0).all()                    # flat channel -> zeros (BatvisionV2_Dataset.py:130-131)
+
+
+def test_uncut_stft_configuration_matches_torch_stft():
+    """The un-cut configuration of BatvisionV2_Dataset.py:96-99 (n_fft 400, win 200, hop 100) against torch.stft, the
+    function torchaudio's Spectrogram delegates to."""
+    rng = np.random.default_rng(9)
+    x = rng.normal(size=(2, 5000)).astype(np.float32)
+    got = fo.stft_mag(x, 100, n_fft=400, win=200)
+    ref = torch.stft(torch.from_numpy(x), n_fft=400, hop_length=100, win_length=200, window=torch.hann_window(200),
+                     center=True, pad_mode='reflect', normalized=False, onesided=True, return_complex=True).abs().numpy()
+    assert got.shape == ref.shape == (2, 201, 51)
+    np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-4)
+    out = fo.bv2_audio_to_input(x, None, 64, 'mel_spectrogram', True)
+    assert out.shape == (2, 64, 64) and out.min() >= 0.0 and out.max() <= 1.0
+    assert fo.mel_fbanks(n_freqs=201).shape == (201, 32)

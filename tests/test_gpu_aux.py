@@ -95,6 +95,27 @@ def test_frontend_bv2(mode, name, antialias):
         assert np.abs(got - ref).mean() <= 1e-4
 
 
+@pytest.mark.parametrize('mode,name', [(3, 'mel_spectrogram'), (4, 'spectrogram')])
+def test_frontend_bv2_uncut_configuration(mode, name):
+    """dataset.max_depth unset: n_fft 400 / win 200 / hop 100 (BatvisionV2_Dataset.py:96-99), modes 3 / 4."""
+    from audio_depth_estimation_amd import kernels as K
+    from audio_depth_estimation_amd._lib import load
+    from audio_depth_estimation_amd.dataloader.utils_dataset import GpuAudioFrontend
+    from oracle import frontend_oracle as fo
+    rng = np.random.default_rng(15)
+    B, T, S = 2, 9000, 128
+    wave = (0.1 * rng.normal(size=(B, 2, T))).astype(np.float32)
+    out = torch.empty(B, 2, S, S, device=DEV)
+    ws = torch.empty(load().adn_frontend_workspace_bytes(B, T, mode) // 4, device=DEV)
+    K.frontend(torch.from_numpy(wave).to(DEV), mode, S, True, out, ws)
+    for b in range(B):
+        ref = fo.bv2_audio_to_input(wave[b], None, S, name, True)
+        got = out[b].cpu().numpy()
+        assert np.abs(got - ref).max() <= 2e-3 and np.abs(got - ref).mean() <= 1e-4
+    fe = GpuAudioFrontend(name + '_uncut', S)
+    assert torch.equal(fe(torch.from_numpy(wave).to(DEV)), out)
+
+
 def test_frontend_bv1_raw_magnitude():
     from audio_depth_estimation_amd import kernels as K
     from audio_depth_estimation_amd._lib import load
@@ -192,7 +213,9 @@ def test_dc_trainer_entry_points_synthetic(which, tmp_path, monkeypatch):
     assert {'epoch', 'model_state_dict', 'optimizer_state_dict'} <= set(ck)
     assert set(ck['model_state_dict']) == set(model.state_dict())
     assert all(torch.isfinite(v).all() for v in ck['model_state_dict'].values() if v.is_floating_point())
-    assert ck['optimizer_state_dict']['step'] == 2 * ck['epoch']             # 8 items / batch 4 = 2 steps per epoch
+    osd = ck['optimizer_state_dict']                                          # torch.optim layout, as the reference saves
+    assert {'state', 'param_groups'} <= set(osd)
+    assert float(osd['state'][0]['step']) == 2 * ck['epoch']                  # 8 items / batch 4 = 2 steps per epoch
     if which == 'rgb':                                                         # resume: continues at epoch 3
         train_dc.main_rgb(common[:4] + ['--nb_epochs', '3', '--experiment_name', 'smoke', '--save_frequency', '1',
                                         '--checkpoints', '2'])

@@ -399,3 +399,46 @@ def test_binaural_final_resize_against_oracle():
         cos = float(torch.dot(got, ref) / (got.norm() * ref.norm() + 1e-30))
         rl2 = float((got - ref).norm() / (ref.norm() + 1e-30))
         assert rl2 <= (5e-2 if got.numel() == 1 else 2e-2) and cos >= 0.9999, (k, rl2, cos)
+
+
+def test_resume_from_a_checkpoint_written_by_the_reference():
+    """tests/golden/ref_ckpt_binaural_bc4.pth was written by the reference's own code path (model.state_dict() +
+    torch.optim.AdamW.state_dict() in the dict layout of train_binaural_attention.py:563-571 after two of its steps).
+    The mirror loads it the way the reference resumes (:358-361) -- model.load_state_dict + the fused trainer's
+    load_state_dict on the torch-format optimizer state -- and its next step must match the reference's third step."""
+    import numpy as np
+    from audio_depth_estimation_amd.engine import FusedTrainer
+    from audio_depth_estimation_amd.models.binaural_attention_model import create_binaural_attention_model
+    ck = torch.load(os.path.join(GOLDEN, 'ref_ckpt_binaural_bc4.pth'), map_location='cpu')
+    z = np.load(os.path.join(GOLDEN, 'ref_ckpt_binaural_bc4_next.npz'))
+    assert set(ck) >= {'epoch', 'model_state_dict', 'optimizer_state_dict'} and ck['epoch'] == 2
+    lr, wd = [float(v) for v in z['hyper']]
+    torch.manual_seed(123)
+    model = create_binaural_attention_model(base_channels=4, bilinear=True, output_size=64, max_depth=30.0,
+                                            attention_levels=[2, 3, 4, 5])
+    model.compute_dtype = torch.float32
+    model.load_state_dict(ck['model_state_dict'])
+    model = model.to(DEV).train()
+    tr = FusedTrainer(model.engine(), 'L1', optimizer='AdamW', lr=lr, weight_decay=wd, clip_norm=None, mask_mode='gt0')
+    tr.load_state_dict(ck['optimizer_state_dict'], DEV)
+    assert int(tr.state[0].item()) == 2
+    before = {k: p.detach().cpu().clone() for k, p in model.named_parameters()}
+    loss, _ = tr.step(torch.from_numpy(z['audio']).to(DEV), torch.from_numpy(z['gt']).to(DEV))
+    assert abs(float(loss) - float(z['loss'])) <= 1e-4 * abs(float(z['loss']))
+    worst = ('', 0.0)
+    for k, p in model.named_parameters():
+        d = (p.detach().cpu() - before[k]).reshape(-1)[:256].numpy()
+        ref = z['delta/' + k]
+        # an AdamW step with restored moments: per-element change <= lr; compare in units of lr
+        err = float(np.abs(d - ref).max()) / lr
+        if _noise_bias(k):                     # zero-gradient parameters: Adam steps on float noise on both sides
+            assert err <= 2.02, (k, err)
+        elif err > worst[1]:
+            worst = (k, err)
+    assert worst[1] <= 0.05, worst
+    # and the state written back is again something the reference's torch optimizer loads
+    sd = tr.state_dict()
+    probe = torch.optim.AdamW([torch.nn.Parameter(torch.zeros_like(p, device='cpu')) for p in model.parameters()], lr=lr,
+                              weight_decay=wd)
+    probe.load_state_dict(sd)
+    assert float(sd['state'][0]['step']) == 3
