@@ -239,7 +239,7 @@ def test_torchrun_entry_point_two_ranks(tmp_path):
     r = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     ck = torch.load(os.path.join(tmp_path, 'results', 'ddp', 'best_model.pth'), map_location='cpu')
-    assert ck['epoch'] == 1 and float(ck['optimizer_state_dict']['state'][0]['step']) == 2
+    assert ck['epoch'] == 1 and float(next(iter(ck['optimizer_state_dict']['state'].values()))['step']) == 2
     assert all(torch.isfinite(v).all() for v in ck['model_state_dict'].values() if v.is_floating_point())
 
 
