@@ -39,6 +39,14 @@ class AdnIgemmDesc(C.Structure):
     ]
 
 
+class AdnMx8ConvDesc(C.Structure):
+    _fields_ = [
+        ('B', c_int32), ('H', c_int32), ('W', c_int32), ('C0', c_int32), ('C1', c_int32), ('N', c_int32),
+        ('in0', c_void_p), ('sc0', c_void_p), ('in1', c_void_p), ('sc1', c_void_p), ('w', c_void_p), ('wsc', c_void_p),
+        ('epi', c_int32), ('reserved', c_int32), ('seg', AdnEpiSeg * 2),
+    ]
+
+
 class AdnWgradDesc(C.Structure):
     _fields_ = [
         ('dtype', c_int32), ('B', c_int32), ('Hs', c_int32), ('Ws', c_int32),
@@ -86,6 +94,10 @@ _PROTOS = {
     'adn_wgrad_workspace_bytes': (c_int64, [C.POINTER(AdnWgradDesc)]),
     'adn_wgrad': (C.c_int, [C.POINTER(AdnWgradDesc), c_void_p]),
     'adn_pack_weights': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    'adn_mx8_quantize': (C.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
+    'adn_mx8_pack': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    'adn_conv3x3_mx8_num_partials': (c_int64, [C.POINTER(AdnMx8ConvDesc)]),
+    'adn_conv3x3_mx8': (C.c_int, [C.POINTER(AdnMx8ConvDesc), c_void_p]),
     'adn_pack_rows': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     'adn_pack_transpose_taps': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                           c_void_p]),

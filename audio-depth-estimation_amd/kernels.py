@@ -12,7 +12,7 @@ import torch
 from . import _lib
 from ._lib import AdnAttnDesc, AdnDistillSmall  # noqa: E402
 from ._lib import (ADN_BF16, ADN_F32, EPI_ACT, EPI_ADD, EPI_BWD, EPI_FINAL, EPI_RAW, EPI_Z_STATS, GEMM_S1, GEMM_S2, GEMM_T2,
-                   AdnEpiSeg, AdnIgemmDesc, AdnWgradDesc, ptr)
+                   AdnEpiSeg, AdnIgemmDesc, AdnMx8ConvDesc, AdnWgradDesc, ptr)
 
 __all__ = ['dtype_code', 'Seg', 'igemm', 'igemm_query', 'wgrad', 'wgrad_workspace_bytes', 'pack_weights',
            'nchw_to_nhwc', 'nhwc_to_nchw', 'bn_fwd_finalize', 'bn_eval_affine', 'bn_act', 'bn_bwd_finalize',
@@ -199,6 +199,53 @@ def pack_transpose_taps(master, X, taps, Y, out, flip=True):
     _dev(master, out)
     _lib.call('adn_pack_transpose_taps', ptr(master), X, taps, Y, int(flip), out.stride(0), dtype_code(out.dtype),
               ptr(out), _stream())
+
+
+# ---- block-scaled fp8 (MX e4m3) 3 x 3 convolution path (csrc/mx8.hip) ------------------------------------------------------
+def mx8_quantize(src, dst8, scales):
+    """src bf16 [..., C] -> dst8 uint8 (e4m3 bits, same shape) + scales uint8 (E8M0) [..., C/32]."""
+    _dev(src, dst8, scales)
+    if src.dtype != torch.bfloat16 or dst8.dtype != torch.uint8 or scales.dtype != torch.uint8:
+        raise TypeError('mx8_quantize: src bf16, dst / scales uint8')
+    Cc = src.shape[-1]
+    _lib.call('adn_mx8_quantize', ptr(src), src.numel() // Cc, Cc, ptr(dst8), ptr(scales), _stream())
+
+
+def mx8_pack_shapes(X, Y, transpose):
+    """(w8 shape, wsc shape) of the packed MX operand of a [X,Y,3,3] conv weight."""
+    rows, kc = (Y, X) if transpose else (X, Y)
+    return (rows, 10, kc), (rows, kc // 64, 5, 4)
+
+
+def mx8_pack(master, X, Y, transpose, w8, wsc):
+    """master f32 [X][9][Y] -> w8 / wsc (see include/adn.h adn_mx8_pack)."""
+    _dev(master, w8, wsc)
+    _lib.call('adn_mx8_pack', ptr(master), X, Y, int(transpose), ptr(w8), ptr(wsc), _stream())
+
+
+def conv3x3_mx8_num_partials(B, H, W):
+    return B * H * W // 128
+
+
+def conv3x3_mx8(B, H, W, in0, sc0, in1, sc1, w8, wsc, N, epi, segs):
+    """3 x 3 stride-1 conv on MX-fp8 operands; outputs / epilogue operands of ``segs`` are bf16 (as igemm)."""
+    d = AdnMx8ConvDesc()
+    d.B, d.H, d.W = B, H, W
+    d.C0 = in0.shape[-1]
+    d.C1 = in1.shape[-1] if in1 is not None else 0
+    d.N = N
+    _dev(in0, sc0, in1, sc1, w8, wsc)
+    d.in0, d.sc0, d.in1, d.sc1, d.w, d.wsc = ptr(in0), ptr(sc0), ptr(in1), ptr(sc1), ptr(w8), ptr(wsc)
+    d.epi = epi
+    segs[0].fill(d.seg[0])
+    if len(segs) > 1:
+        segs[1].fill(d.seg[1])
+    ev = _prof_begin()
+    _lib.call('adn_conv3x3_mx8', C.byref(d), _stream())
+    flops = 2.0 * B * H * W * N * 9 * (d.C0 + d.C1)
+    _lib.annotate(label='conv3x3_mx8', flops=flops)
+    if ev is not None:
+        _prof_end(ev, 'conv3x3_mx8', flops)
 
 
 def nchw_to_nhwc(src, dst):

@@ -146,6 +146,33 @@ int adn_pack_rows(const float* master, int32_t X, int32_t taps, int32_t Y, int32
 int adn_pack_transpose_taps(const float* master, int32_t X, int32_t taps, int32_t Y, int32_t flip,
                             int32_t row_stride, int32_t dtype, void* out, void* stream);
 
+/* ---- Block-scaled fp8 (OCP MX: e4m3 elements + one E8M0 scale byte per 32 channels) path of the 3 x 3 stride-1
+ * convolutions (BASELINE config 5: models/rgb_depth_model.py:21-77 DoubleConv / Down / Up at 512 x 512; forward of
+ * nn.Conv2d(k3, p1) and its input-gradient pass inside loss.backward()).  v_mfma_scale_f32_16x16x128_f8f6f4; outputs
+ * and epilogues in bf16 exactly as adn_igemm with dtype ADN_BF16, geometry ADN_GEMM_S1, ks 3. ---- */
+/* bf16 [rows][C] -> e4m3 [rows][C] + E8M0 [rows][C/32]  (C % 32 == 0, rows*C % 128 == 0). */
+int adn_mx8_quantize(const void* src_bf16, int64_t rows, int32_t C, void* dst_e4m3, void* scales_e8m0, void* stream);
+/* f32 master [X][9][Y] (channels_last memory of an [X,Y,3,3] Conv2d weight) -> packed operand of adn_conv3x3_mx8:
+ *   transpose 0 (forward):        w8 [X][10][Y],  blocks of 32 along Y;  wsc [X][Y/64][5][4]
+ *   transpose 1 (input gradient): w8 [Y][10][X],  taps flipped, blocks of 32 along X;  wsc [Y][X/64][5][4]
+ * (tap 9 is an all-zero padding tap: 9 taps = 4.5 K-steps of 2 taps.) */
+int adn_mx8_pack(const float* master, int32_t X, int32_t Y, int32_t transpose, void* w8, void* wsc, void* stream);
+typedef struct {
+  int32_t B, H, W;     /* common grid of input and output (H % 8 == 0, W % 16 == 0)                 */
+  int32_t C0, C1, N;   /* gathered sources (virtual concat, multiples of 64; C1 may be 0), outputs  */
+  const void* in0;     /* e4m3 [B][H][W][C0]                                                       */
+  const void* sc0;     /* E8M0 [B][H][W][C0/32]                                                    */
+  const void* in1;
+  const void* sc1;
+  const void* w;       /* adn_mx8_pack w8                                                          */
+  const void* wsc;     /* adn_mx8_pack wsc                                                         */
+  int32_t epi;         /* ADN_EPI_Z_STATS / ADN_EPI_ACT / ADN_EPI_BWD / ADN_EPI_ADD                 */
+  int32_t reserved;
+  AdnEpiSeg seg[2];    /* bf16 tensors                                                             */
+} AdnMx8ConvDesc;
+int64_t adn_conv3x3_mx8_num_partials(const AdnMx8ConvDesc* d);   /* stats partial rows = B*H*W / 128 */
+int adn_conv3x3_mx8(const AdnMx8ConvDesc* d, void* stream);
+
 /* ---- DoubleConv U-Net family (DoubleConv / Down / Up: binaural_attention_model.py:22-78, identical copies
  * rgb_depth_model.py:21-77, adabins_distillation_model.py:27-82).  NHWC activations in dtype. ---- */
 /* nn.MaxPool2d(2): src [B][H][W][C] -> dst [B][H/2][W/2][C]; backward routes each window's gradient to its
