@@ -2,6 +2,7 @@
 // conversion, BatchNorm finalize / apply passes.  All are streaming kernels (HBM roofline),
 // 16-byte accesses where the layout allows, grid capped at ~2048 blocks with grid-stride loops.
 #include "epilogue.h"
+#include "mx8_quant.h"
 
 namespace {
 
@@ -267,7 +268,8 @@ __global__ __launch_bounds__(256) void bn_eval_affine_kernel(const float* gamma,
 // y = z*scale+shift -> leaky / relu copies.  8 channels (one or two 16-byte chunks) per thread.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_act_kernel(const T* z, int64_t pixels, int C, const float* scale,
-                                                     const float* shift, float slope, T* out_leaky, T* out_relu) {
+                                                     const float* shift, float slope, T* out_leaky, T* out_relu,
+                                                     uint2* q8 = nullptr, uint8_t* qsc = nullptr) {
   const int64_t n = pixels * C;
   if ((C & 7) == 0) {
     const int64_t groups = n >> 3;
@@ -293,6 +295,15 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* z, int64_t pixels,
 #pragma unroll
         for (int k = 0; k < 8; ++k) o[k] = fmaxf(v[k], 0.f);
         store8<T>(out_relu, e, o);
+        if constexpr (sizeof(T) == 2) {
+          if (q8) {                                  // MX-fp8 copy of exactly what the bf16 tensor holds (C % 32 == 0)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = bf16_bits_to_f32(f32_to_bf16_bits(o[k]));
+            int byte;
+            q8[gidx] = mx_quant8(o, byte);
+            if ((threadIdx.x & 3) == 0) qsc[gidx >> 2] = (uint8_t)byte;
+          }
+        }
       }
     }
   } else {
@@ -321,7 +332,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* parti
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(T* g, const T* z, int64_t pixels, int C,
                                                            const float* scale, const float* mean, const float* istd,
-                                                           const float* coef) {
+                                                           const float* coef, uint2* q8 = nullptr, uint8_t* qsc = nullptr) {
   const int64_t n = pixels * C;
   if ((C & 7) == 0) {
     const int64_t groups = n >> 3;
@@ -342,6 +353,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(T* g, const T* z, int
         gv[k] = scale[c + k] * (gv[k] - coef[c + k] - xh * coef[C + c + k]);
       }
       store8<T>(g, e, gv);
+      if constexpr (sizeof(T) == 2) {
+        if (q8) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) gv[k] = bf16_bits_to_f32(f32_to_bf16_bits(gv[k]));
+          int byte;
+          q8[gidx] = mx_quant8(gv, byte);
+          if ((threadIdx.x & 3) == 0) qsc[gidx >> 2] = (uint8_t)byte;
+        }
+      }
     }
   } else {
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
@@ -615,6 +635,31 @@ extern "C" int adn_bn_act(const void* z, int64_t pixels, int32_t C, int32_t dtyp
     hipLaunchKernelGGL((bn_act_kernel<float>), dim3(blocks_for(work)), dim3(256), 0, st,
                        reinterpret_cast<const float*>(z), pixels, C, scale, shift, slope,
                        reinterpret_cast<float*>(out_leaky), reinterpret_cast<float*>(out_relu));
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}
+
+// BN apply + ReLU with an additional MX-fp8 copy (e4m3 + E8M0 per 32 channels) of the bf16 output, for the fp8 conv path.
+extern "C" int adn_bn_act_mx8(const void* z, int64_t pixels, int32_t C, const float* scale, const float* shift,
+                              void* out_relu, void* out8, void* out_scales, void* stream) {
+  ADN_CHECK_ARG(z && pixels > 0 && C > 0 && C % 32 == 0 && scale && shift && out_relu && out8 && out_scales,
+                "adn_bn_act_mx8: bad arguments (C=%d must be a multiple of 32)", C);
+  hipLaunchKernelGGL((bn_act_kernel<uint16_t>), dim3(blocks_for(pixels * C / 8)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const uint16_t*>(z), pixels, C, scale, shift, 0.f,
+                     (uint16_t*)nullptr, reinterpret_cast<uint16_t*>(out_relu), reinterpret_cast<uint2*>(out8),
+                     reinterpret_cast<uint8_t*>(out_scales));
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}
+
+extern "C" int adn_bn_bwd_apply_mx8(void* g, const void* z, int64_t pixels, int32_t C, const float* scale, const float* mean,
+                                    const float* istd, const float* coef, void* out8, void* out_scales, void* stream) {
+  ADN_CHECK_ARG(g && z && pixels > 0 && C > 0 && C % 32 == 0 && scale && mean && istd && coef && out8 && out_scales,
+                "adn_bn_bwd_apply_mx8: bad arguments (C=%d must be a multiple of 32)", C);
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<uint16_t>), dim3(blocks_for(pixels * C / 8)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<uint16_t*>(g),
+                     reinterpret_cast<const uint16_t*>(z), pixels, C, scale, mean, istd, coef,
+                     reinterpret_cast<uint2*>(out8), reinterpret_cast<uint8_t*>(out_scales));
   ADN_CHECK_LAUNCH();
   return ADN_OK;
 }

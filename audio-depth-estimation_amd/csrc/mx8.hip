@@ -26,6 +26,7 @@
 #include <math.h>
 
 #include "epilogue.h"
+#include "mx8_quant.h"
 
 namespace {
 
@@ -36,34 +37,6 @@ __device__ __forceinline__ int xcd_remap8(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
-// ---- MX quantisation of one 32-element block -------------------------------------------------------------------------
-// E8M0 byte of a block with absolute maximum amax: the smallest power of two >= amax / 448, so that no element
-// saturates (amax = m 2^e: 2^(e-8) when m <= 1.75, else 2^(e-7); the floor rule of the OCP MX v1.0 text, 2^(e-8) always,
-// clips the elements with m > 1.75 by up to 12.5 %).
-__device__ __forceinline__ int mx_scale_byte(float amax) {
-  if (!(amax > 0.f)) return 0;
-  const uint32_t b = __float_as_uint(amax);
-  int e = (int)((b >> 23) & 0xff) - 8 + ((b & 0x7fffffu) > 0x600000u ? 1 : 0);   // denormal f32 -> 2^-127
-  return e < 0 ? 0 : (e > 254 ? 254 : e);
-}
-// 2^(127 - byte) as a float factor applied in two exact halves (the full factor can exceed the f32 range)
-__device__ __forceinline__ float mx_descale(float v, int byte) {
-  const int k = 127 - byte;                                   // -127 .. 127
-  const int k1 = k / 2, k2 = k - k1;
-  return v * __uint_as_float((unsigned)(127 + k1) << 23) * __uint_as_float((unsigned)(127 + k2) << 23);
-}
-// round-to-nearest-even e4m3fn with saturation at +-448 (the hardware cast; clamped first: |v| < 512 can exceed 448)
-__device__ __forceinline__ uint32_t cvt4_e4m3(float a, float b, float c, float d) {
-  a = fminf(fmaxf(a, -448.f), 448.f);
-  b = fminf(fmaxf(b, -448.f), 448.f);
-  c = fminf(fmaxf(c, -448.f), 448.f);
-  d = fminf(fmaxf(d, -448.f), 448.f);
-  int r = 0;
-  r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, r, false);
-  r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
-  return (uint32_t)r;
-}
-
 // bf16 [rows][C] -> e4m3 + scales.  One thread per 8 channels (16-byte load, 8-byte store), 4 threads per block.
 __global__ __launch_bounds__(256) void mx8_quant_kernel(const uint16_t* __restrict__ src, int64_t chunks, uint2* __restrict__ dst,
                                                         uint8_t* __restrict__ sc) {
@@ -72,17 +45,8 @@ __global__ __launch_bounds__(256) void mx8_quant_kernel(const uint16_t* __restri
     const u32x4_t raw = *reinterpret_cast<const u32x4_t*>(src + i * 8);
     float f[8];
     Chunk<uint16_t>::unpack(raw, f);
-    float am = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) am = fmaxf(am, fabsf(f[e]));
-    am = fmaxf(am, __shfl_xor(am, 1, 64));
-    am = fmaxf(am, __shfl_xor(am, 2, 64));
-    const int byte = mx_scale_byte(am);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) f[e] = mx_descale(f[e], byte);
-    uint2 o;
-    o.x = cvt4_e4m3(f[0], f[1], f[2], f[3]);
-    o.y = cvt4_e4m3(f[4], f[5], f[6], f[7]);
+    int byte;
+    const uint2 o = mx_quant8(f, byte);
     dst[i] = o;
     if ((threadIdx.x & 3) == 0) sc[i >> 2] = (uint8_t)byte;
   }
@@ -90,7 +54,9 @@ __global__ __launch_bounds__(256) void mx8_quant_kernel(const uint16_t* __restri
 
 // weights: one thread per (row, tap 0..9, 32-block of the contraction channels)
 //   transpose == 0: row = x (output channel), contraction = y:  v = master[row][tap][k]
+//                   (threads run along the blocks of a row: each reads 128 contiguous bytes, neighbours adjacent)
 //   transpose == 1: row = y (input channel), contraction = x, taps flipped:  v = master[k][8 - tap][row]
+//                   (threads run along the rows: for every k the 64 lanes read 64 consecutive floats)
 __global__ __launch_bounds__(256) void mx8_pack_kernel(const float* __restrict__ master, int X, int Y, int transpose,
                                                        uint8_t* __restrict__ w8, uint8_t* __restrict__ wsc) {
   const int rows = transpose ? Y : X, Kc = transpose ? X : Y;
@@ -98,25 +64,49 @@ __global__ __launch_bounds__(256) void mx8_pack_kernel(const float* __restrict__
   const int64_t total = (int64_t)rows * 10 * nblk;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
-  const int blk = (int)(i % nblk);
-  const int tap = (int)((i / nblk) % 10);
-  const int row = (int)(i / ((int64_t)nblk * 10));
+  int blk, tap, row;
+  if (transpose) {
+    row = (int)(i % rows);
+    blk = (int)((i / rows) % nblk);
+    tap = (int)(i / ((int64_t)rows * nblk));
+  } else {
+    blk = (int)(i % nblk);
+    tap = (int)((i / nblk) % 10);
+    row = (int)(i / ((int64_t)nblk * 10));
+  }
   float v[32];
   float am = 0.f;
+  if (tap < 9) {
+    if (transpose) {
+      const float* src = master + ((int64_t)blk * 32 * 9 + (8 - tap)) * Y + row;
 #pragma unroll
-  for (int j = 0; j < 32; ++j) {
-    const int k = blk * 32 + j;
-    float t = 0.f;
-    if (tap < 9) t = transpose ? master[((int64_t)k * 9 + (8 - tap)) * Y + row] : master[((int64_t)row * 9 + tap) * Y + k];
-    v[j] = t;
-    am = fmaxf(am, fabsf(t));
+      for (int j = 0; j < 32; ++j) v[j] = src[(int64_t)j * 9 * Y];
+    } else {
+      const f32x4_t* src = reinterpret_cast<const f32x4_t*>(master + ((int64_t)row * 9 + tap) * Y + blk * 32);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const f32x4_t t = src[j];
+        v[4 * j] = t[0];
+        v[4 * j + 1] = t[1];
+        v[4 * j + 2] = t[2];
+        v[4 * j + 3] = t[3];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 32; ++j) am = fmaxf(am, fabsf(v[j]));
+  } else {
+#pragma unroll
+    for (int j = 0; j < 32; ++j) v[j] = 0.f;
   }
   const int byte = tap < 9 ? mx_scale_byte(am) : 127;
-  uint32_t* o = reinterpret_cast<uint32_t*>(w8 + ((int64_t)row * 10 + tap) * Kc + blk * 32);
+  u32x4_t* o = reinterpret_cast<u32x4_t*>(w8 + ((int64_t)row * 10 + tap) * Kc + blk * 32);
+  u32x4_t q[2];
 #pragma unroll
   for (int j = 0; j < 8; ++j)
-    o[j] = cvt4_e4m3(mx_descale(v[4 * j], byte), mx_descale(v[4 * j + 1], byte), mx_descale(v[4 * j + 2], byte),
-                     mx_descale(v[4 * j + 3], byte));
+    q[j >> 2][j & 3] = cvt4_e4m3(mx_descale(v[4 * j], byte), mx_descale(v[4 * j + 1], byte), mx_descale(v[4 * j + 2], byte),
+                                 mx_descale(v[4 * j + 3], byte));
+  o[0] = q[0];
+  o[1] = q[1];
   // scale layout [row][chunk = blk >> 1][pair = tap >> 1][(tap & 1) * 2 + (blk & 1)]: the 4 bytes of a K-step are one dword
   wsc[(((int64_t)row * (nblk >> 1) + (blk >> 1)) * 5 + (tap >> 1)) * 4 + (tap & 1) * 2 + (blk & 1)] = (uint8_t)byte;
 }

@@ -46,6 +46,9 @@ class Act:
         self.bpart_rows = 0
         self.alias_of = None         # this record's gradient IS that record's gradient buffer (gated residual)
         self.pair_data = self.pair_grad = None      # [2B,...] buffers when stacked with a sibling ([left; right])
+        self.q8 = self.q8s = None    # MX-fp8 copy of .data (e4m3 bytes + E8M0 scales) for the fp8 conv path
+        self.q8_serial = -1          # forward pass the copy belongs to
+        self.want_q8 = False         # some consumer is an MX-fp8 conv: the producer writes the copy with its output
 
     def target(self):
         return self.alias_of if self.alias_of is not None else self
@@ -145,12 +148,32 @@ class ConvBNReLU(Op):
         self.scale, self.shift = torch.empty(N, **f32), torch.empty(N, **f32)
         self.coef = torch.empty(2 * N, **f32)
         H, W = o.H, o.W
+        # MX-fp8 variant of this layer (engine in fp8 mode): 3 x 3, every channel count a multiple of 64, image tileable
+        # by 8 x 16 pixels; other layers (the thin first conv, 1 x 1 convs) stay on the bf16 kernels
+        self.mx8 = bool(eng.mx8 and self.ks == 3 and not self.padded and self.cin_real == cin and self.c0 % 64 == 0 and
+                        self.c1 % 64 == 0 and N % 64 == 0 and H % 8 == 0 and W % 16 == 0)
+        u8 = dict(dtype=torch.uint8, device=dev)
+        if self.mx8:
+            s8, ssc = K.mx8_pack_shapes(N, cin, False)
+            self.w8_fwd, self.wsc_fwd = torch.empty(s8, **u8), torch.empty(ssc, **u8)
+            if self.need_dgrad:
+                s8, ssc = K.mx8_pack_shapes(N, cin, True)
+                self.w8_dg, self.wsc_dg = torch.empty(s8, **u8), torch.empty(ssc, **u8)
+                self.g8, self.g8s = torch.empty(B, H, W, N, **u8), torch.empty(B, H, W, N // 32, **u8)
+            for s_ in self.srcs:
+                s_.want_q8 = True
+                if s_.q8 is None:
+                    s_.q8, s_.q8s = torch.empty(B, s_.H, s_.W, s_.C, **u8), torch.empty(B, s_.H, s_.W, s_.C // 32, **u8)
         self.P, ws1 = K.igemm_query(T, GEMM_S1, B, H, W, self.c0, self.c1, N, [N], ks=self.ks)
+        if self.mx8:
+            self.P, ws1 = K.conv3x3_mx8_num_partials(B, H, W), 0
         self.part = torch.empty(self.P * 2 * N, **f32)
         ws2 = 0
         if self.need_dgrad:
             segc = [self.c0, self.c1] if self.c1 else [self.c0]
             pg, ws2 = K.igemm_query(T, GEMM_S1, B, H, W, N, 0, cin, segc, ks=self.ks)
+            if self.mx8:
+                pg, ws2 = K.conv3x3_mx8_num_partials(B, H, W), 0
             for s in self.srcs:
                 if s.fused_bwd:
                     s.bpart_rows = pg
@@ -178,6 +201,11 @@ class ConvBNReLU(Op):
             if self.bias_p is not None:
                 K.pack_rows(eng._flat_slice(eng.flat_p, self.conv.bias), nr, 1, 1, self.bias_p[:nr])
             master = self.wm_p
+        if self.mx8:
+            K.mx8_pack(master, self.N, self.cin_real, False, self.w8_fwd, self.wsc_fwd)
+            if self.need_dgrad:
+                K.mx8_pack(master, self.N, self.cin_real, True, self.w8_dg, self.wsc_dg)
+            return
         if not self.fwd_is_view:
             K.pack_rows(master, self.N, taps, self.cin_real, self.w_fwd, y_pad=self.c0 + self.c1)
         if self.w_dg is not None:
@@ -198,15 +226,32 @@ class ConvBNReLU(Op):
         bn, N = self.bn, self.N
         pixels = B * o.H * o.W
         gamma, beta, rmean, rvar, cbias = self._bn_vectors()
+        if self.mx8:
+            q0, s0 = eng.q8_of(self.srcs[0])
+            q1, s1 = eng.q8_of(self.srcs[1]) if self.c1 else (None, None)
         if training:
-            K.igemm(T, GEMM_S1, B, o.H, o.W, in0, in1, self.w_fwd, N, EPI_Z_STATS,
-                    [K.Seg(N, out0=o.z, partials=self.part, bias=cbias)], eng.workspace,
-                    algo_c=self.cin_real, ks=self.ks)
+            if self.mx8:
+                K.conv3x3_mx8(B, o.H, o.W, q0, s0, q1, s1, self.w8_fwd, self.wsc_fwd, N, EPI_Z_STATS,
+                              [K.Seg(N, out0=o.z, partials=self.part, bias=cbias)])
+            else:
+                K.igemm(T, GEMM_S1, B, o.H, o.W, in0, in1, self.w_fwd, N, EPI_Z_STATS,
+                        [K.Seg(N, out0=o.z, partials=self.part, bias=cbias)], eng.workspace,
+                        algo_c=self.cin_real, ks=self.ks)
             K.bn_fwd_finalize(self.part, self.P, N, pixels, gamma, beta, bn.eps,
                               BN_MOMENTUM if bn.momentum is None else bn.momentum, rmean, rvar,
                               bn.num_batches_tracked if rmean is not None else None, o.mean, o.istd, self.scale,
                               self.shift)
-            K.bn_act(o.z, pixels, N, self.scale, self.shift, 0.0, None, o.data)
+            if o.want_q8 and N % 32 == 0:             # a consumer is an fp8 conv: its operand copy comes with the output
+                K.bn_act_mx8(o.z, pixels, N, self.scale, self.shift, o.data, o.q8, o.q8s)
+                o.q8_serial = eng.fwd_serial
+            else:
+                K.bn_act(o.z, pixels, N, self.scale, self.shift, 0.0, None, o.data)
+        elif self.mx8:
+            K.bn_eval_affine(gamma, beta, rmean, rvar, bn.eps, self.scale, self.shift)
+            if cbias is not None:
+                self.shift.addcmul_(cbias.detach(), self.scale)
+            K.conv3x3_mx8(B, o.H, o.W, q0, s0, q1, s1, self.w8_fwd, self.wsc_fwd, N, EPI_ACT,
+                          [K.Seg(N, out1=o.data, scale=self.scale, shift=self.shift)])
         else:
             K.bn_eval_affine(gamma, beta, rmean, rvar, bn.eps, self.scale, self.shift)
             if cbias is not None:                             # BN(conv + b) = conv * scale + (shift + b * scale)
@@ -229,7 +274,10 @@ class ConvBNReLU(Op):
             K.pack_rows(self.dbeta_p[:self.n_real], self.n_real, 1, 1, fg(bn.bias))
         else:
             K.bn_bwd_finalize(o.bpart, o.bpart_rows, N, pixels, fg(bn.weight), fg(bn.bias), self.coef)
-        K.bn_bwd_apply(G, o.z, pixels, N, self.scale, o.mean, o.istd, self.coef)      # G is now d loss / d z
+        if self.mx8 and self.need_dgrad:                 # G is now d loss / d z (+ its fp8 copy for the input-gradient GEMM)
+            K.bn_bwd_apply_mx8(G, o.z, pixels, N, self.scale, o.mean, o.istd, self.coef, self.g8, self.g8s)
+        else:
+            K.bn_bwd_apply(G, o.z, pixels, N, self.scale, o.mean, o.istd, self.coef)      # G is now d loss / d z
         eng._mark(bn.weight, bn.bias)
         if self.conv.bias is not None:
             # a bias in front of BatchNorm has an identically zero gradient (BN subtracts the batch mean); the
@@ -258,7 +306,10 @@ class ConvBNReLU(Op):
             else:
                 segs.append(K.Seg(s.C, out0=s.grad if s.needs_grad else eng.scratch_like(s), accumulate=tgt.written))
             tgt.written = True
-        K.igemm(T, GEMM_S1, B, o.H, o.W, G, None, self.w_dg, self.c0 + self.c1, epi, segs, eng.workspace, ks=self.ks)
+        if self.mx8:
+            K.conv3x3_mx8(B, o.H, o.W, self.g8, self.g8s, None, None, self.w8_dg, self.wsc_dg, self.c0 + self.c1, epi, segs)
+        else:
+            K.igemm(T, GEMM_S1, B, o.H, o.W, G, None, self.w_dg, self.c0 + self.c1, epi, segs, eng.workspace, ks=self.ks)
 
 
 class MaxPool2(Op):
@@ -589,7 +640,13 @@ class DCEngine(FlatParamEngine):
     def __init__(self, module, build, compute_dtype=torch.bfloat16, model_name='model'):
         self.module = module
         self._build = build
-        self.dtype = compute_dtype
+        # compute_dtype torch.float8_e4m3fn = BASELINE config 5's precision: the 3 x 3 convolutions' forward and
+        # input-gradient GEMMs run block-scaled fp8 (MX e4m3, csrc/mx8.hip); storage, BatchNorm, the weight-gradient
+        # GEMMs and every other op stay bf16
+        self.requested_dtype = compute_dtype
+        self.mx8 = compute_dtype == torch.float8_e4m3fn
+        self.dtype = torch.bfloat16 if self.mx8 else compute_dtype
+        self.fwd_serial = 0
         self.model_name = model_name
         self.depth_norm = False
         self._init_flat()
@@ -602,6 +659,14 @@ class DCEngine(FlatParamEngine):
         if key not in self._scratch:
             self._scratch[key] = torch.empty(self.B, act.H, act.W, act.C, dtype=self.dtype, device=self.dev)
         return self._scratch[key]
+
+    def q8_of(self, act):
+        """(e4m3 bytes, E8M0 scales) of ``act.data`` for the current forward pass; quantised here unless the producer
+        already wrote the copy together with its output."""
+        if act.q8_serial != self.fwd_serial:
+            K.mx8_quantize(act.data, act.q8, act.q8s)
+            act.q8_serial = self.fwd_serial
+        return act.q8, act.q8s
 
     def _prepare(self, x):
         if not self._bound():
@@ -668,6 +733,7 @@ class DCEngine(FlatParamEngine):
         self._prepare(x)
         if self.weights_dirty or self._packed_version != self._version_sum():
             self._pack_weights()
+        self.fwd_serial += 1
         self.load_input(x)
         for op in self.ops:
             op.fwd(self, training)

@@ -39,7 +39,7 @@ class FlatParamEngine:
     # ``_shape_sets`` and swapped in O(1).  Everything an engine assigns in its _prepare*() is per-shape state;
     # the names below are the shape-independent ones.
     _SHAPE_INDEPENDENT = frozenset((
-        'module', 'dtype', 'model_name', 'depth_norm', 'n', 'levels', '_build', '_saved', 'flat_p', 'flat_g', 'flat_w16',
+        'module', 'dtype', 'requested_dtype', 'mx8', 'model_name', 'depth_norm', 'n', 'levels', '_build', '_saved', 'flat_p', 'flat_g', 'flat_w16',
         'param_meta', 'total', 'offset', 'on_grad_ready', '_shape_key', '_shape_sets', '_packed_version',
         'weights_dirty', 's2_fresh', 'train_offset', 'step_counter', 'dropout_seed'))
     MAX_SHAPE_SETS = 4

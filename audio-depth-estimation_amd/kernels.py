@@ -211,6 +211,20 @@ def mx8_quantize(src, dst8, scales):
     _lib.call('adn_mx8_quantize', ptr(src), src.numel() // Cc, Cc, ptr(dst8), ptr(scales), _stream())
 
 
+def bn_act_mx8(z, pixels, Cc, scale, shift, out_relu, out8, out_scales):
+    """bn_act (BN affine + ReLU, bf16) that also writes the MX-fp8 copy of its output."""
+    _dev(z, scale, shift, out_relu, out8, out_scales)
+    _lib.call('adn_bn_act_mx8', ptr(z), pixels, Cc, ptr(scale), ptr(shift), ptr(out_relu), ptr(out8), ptr(out_scales),
+              _stream())
+
+
+def bn_bwd_apply_mx8(g, z, pixels, Cc, scale, mean, istd, coef, out8, out_scales):
+    """bn_bwd_apply (in place on g, bf16) that also writes the MX-fp8 copy of the resulting d loss / d z."""
+    _dev(g, z, scale, mean, istd, coef, out8, out_scales)
+    _lib.call('adn_bn_bwd_apply_mx8', ptr(g), ptr(z), pixels, Cc, ptr(scale), ptr(mean), ptr(istd), ptr(coef), ptr(out8),
+              ptr(out_scales), _stream())
+
+
 def mx8_pack_shapes(X, Y, transpose):
     """(w8 shape, wsc shape) of the packed MX operand of a [X,Y,3,3] conv weight."""
     rows, kc = (Y, X) if transpose else (X, Y)

@@ -127,7 +127,7 @@ class AdaBinsDistillationModel(nn.Module):
 
     def engine(self):
         from ..adabins_engine import AdaBinsEngine
-        if self._engine is None or self._engine.dtype != self.compute_dtype:
+        if self._engine is None or self._engine.requested_dtype != self.compute_dtype:
             object.__setattr__(self, '_engine', AdaBinsEngine(self, self.compute_dtype))
         return self._engine
 

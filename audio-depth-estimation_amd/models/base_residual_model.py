@@ -56,7 +56,7 @@ class BaseResidualDepthNet(nn.Module):
 
     def engine(self):
         from ..base_residual_engine import BaseResidualEngine
-        if self._engine is None or self._engine.dtype != self.compute_dtype:
+        if self._engine is None or self._engine.requested_dtype != self.compute_dtype:
             object.__setattr__(self, '_engine', BaseResidualEngine(self, self.compute_dtype))
         return self._engine
 

@@ -141,7 +141,7 @@ class BinauralAttentionDepthNet(nn.Module):
         return [(left, 0, 1), (right, 1, 1)], ops, head
 
     def engine(self):
-        if self._engine is None or self._engine.dtype != self.compute_dtype:
+        if self._engine is None or self._engine.requested_dtype != self.compute_dtype:
             object.__setattr__(self, '_engine', DCEngine(self, self._adn_build, self.compute_dtype,
                                                          'BinauralAttentionDepthNet'))
         return self._engine

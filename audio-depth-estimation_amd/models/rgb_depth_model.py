@@ -153,7 +153,7 @@ class RGBDepthNet(nn.Module):
         return [(x, 0, 3)], ops, head
 
     def engine(self):
-        if self._engine is None or self._engine.dtype != self.compute_dtype:
+        if self._engine is None or self._engine.requested_dtype != self.compute_dtype:
             object.__setattr__(self, '_engine', DCEngine(self, self._adn_build, self.compute_dtype, 'RGBDepthNet'))
         return self._engine
 

@@ -7,7 +7,7 @@ optimizer_state_dict, ...``; AdaBins: ``./results/<experiment>/``), its loop ord
 ``compute_errors`` -> scheduler step -> checkpoints) and its loss / optimizer / scheduler choices; the per-batch body
 (forward, loss, backward, [clip], optimizer step) is ONE fused libadn step (engine.FusedTrainer /
 adabins_engine.AdaBinsTrainer).  Extra flags: ``--synthetic N`` (BatVision-shaped random items; no
-dataset is needed), ``--precision bf16|f32``.  wandb / visualisation plumbing is out of scope.
+dataset is needed), ``--precision bf16|f32|mxfp8`` (mxfp8: block-scaled fp8 3 x 3 conv forward / input-gradient GEMMs, BASELINE config 5).  wandb / visualisation plumbing is out of scope.
 Thin launchers with the reference's script names live next to this file.
 
 Multi-GPU: where the reference wraps the model in ``nn.DataParallel(gpu_ids)``, launch these with torchrun (one
@@ -74,7 +74,7 @@ def _common_flags(p, lr, batch):
     p.add_argument('--device', type=str, default='cuda')
     p.add_argument('--seed', type=int, default=42)
     p.add_argument('--synthetic', type=int, default=0, help='train on N BatVision-shaped random items')
-    p.add_argument('--precision', type=str, default='bf16', choices=['bf16', 'f32'])
+    p.add_argument('--precision', type=str, default='bf16', choices=['bf16', 'f32', 'mxfp8'])
 
 
 def _dist():
@@ -159,7 +159,7 @@ def _run(args, cfg, model, trainer, kind, step, forward, exp, ckpt_root='checkpo
     rank, world, local, reducer = dist_info
     dev = _device(args, local if world > 1 else None)
     torch.manual_seed(args.seed)
-    model.compute_dtype = torch.bfloat16 if args.precision == 'bf16' else torch.float32
+    model.compute_dtype = {'bf16': torch.bfloat16, 'f32': torch.float32, 'mxfp8': torch.float8_e4m3fn}[args.precision]
     model = model.to(dev).train()
     tl, vl, sampler, fe = _loaders(cfg, args, kind, rank, world)
     ckpt_dir = os.path.join(ckpt_root, exp)
@@ -300,7 +300,7 @@ def main_adabins(argv=None):
     p.add_argument('--wandb_entity', type=str, default='branden')
     p.add_argument('--gpu_ids', type=str, default='0')
     p.add_argument('--synthetic', type=int, default=0)
-    p.add_argument('--precision', type=str, default='bf16', choices=['bf16', 'f32'])
+    p.add_argument('--precision', type=str, default='bf16', choices=['bf16', 'f32', 'mxfp8'])
     args = p.parse_args(argv)
     cfg = load_config(dataset_name=args.dataset, model_name='unet_baseline', mode='train', experiment_name=args.experiment_name)
     if args.max_depth is not None:
@@ -372,7 +372,7 @@ def main_base_residual(argv=None):
     p.add_argument('--experiment_name', type=str, default='base_res_default')
     p.add_argument('--checkpoints', type=int, default=None)
     p.add_argument('--synthetic', type=int, default=0)
-    p.add_argument('--precision', type=str, default='bf16', choices=['bf16', 'f32'])
+    p.add_argument('--precision', type=str, default='bf16', choices=['bf16', 'f32', 'mxfp8'])
     args = p.parse_args(argv)
     cfg = load_config(dataset_name=args.dataset, model_name='unet_baseline', mode='train', experiment_name=args.experiment_name)
     cfg.dataset.audio_format = args.audio_format

@@ -157,6 +157,12 @@ int adn_mx8_quantize(const void* src_bf16, int64_t rows, int32_t C, void* dst_e4
  *   transpose 1 (input gradient): w8 [Y][10][X],  taps flipped, blocks of 32 along X;  wsc [Y][X/64][5][4]
  * (tap 9 is an all-zero padding tap: 9 taps = 4.5 K-steps of 2 taps.) */
 int adn_mx8_pack(const float* master, int32_t X, int32_t Y, int32_t transpose, void* w8, void* wsc, void* stream);
+/* The producers of the fp8 path: adn_bn_act / adn_bn_bwd_apply (below) that ALSO write the MX-fp8 copy of their bf16
+ * result (bit-identical to adn_mx8_quantize of that result), saving one pass over the tensor.  C % 32 == 0. */
+int adn_bn_act_mx8(const void* z, int64_t pixels, int32_t C, const float* scale, const float* shift, void* out_relu,
+                   void* out8, void* out_scales, void* stream);
+int adn_bn_bwd_apply_mx8(void* g, const void* z, int64_t pixels, int32_t C, const float* scale, const float* mean,
+                         const float* istd, const float* coef, void* out8, void* out_scales, void* stream);
 typedef struct {
   int32_t B, H, W;     /* common grid of input and output (H % 8 == 0, W % 16 == 0)                 */
   int32_t C0, C1, N;   /* gathered sources (virtual concat, multiples of 64; C1 may be 0), outputs  */

@@ -83,12 +83,13 @@ def main():
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--base', type=int, default=64)
     ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32', 'mxfp8'],
+                    help='mxfp8: 3x3 conv forward / input-gradient GEMMs in block-scaled fp8 (DoubleConv nets only)')
     ap.add_argument('--detail', action='store_true', help='list every GEMM launch')
     args = ap.parse_args()
     from audio_depth_estimation_amd.engine import FusedTrainer
     dev = torch.device('cuda', 0)
-    dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    dtype = {'bf16': torch.bfloat16, 'f32': torch.float32, 'mxfp8': torch.float8_e4m3fn}[args.dtype]
     torch.manual_seed(0)
     B, S = args.batch, args.size
     g = torch.Generator().manual_seed(1)

@@ -64,10 +64,14 @@ def main():
     ap.add_argument('--bwd', action='store_true')
     ap.add_argument('--b2', type=int, default=8)
     ap.add_argument('--s1', action='store_true', help='stride-1 3x3 shapes of the DoubleConv nets instead')
+    ap.add_argument('--mx8', action='store_true', help='MX-fp8 3x3 conv beside the bf16 patch kernel (config 5 shapes)')
+    ap.add_argument('--b', type=int, default=0, help='batch for --mx8 (default 8)')
     ap.add_argument('--deep', action='store_true', help='the small-M split-K layers of unet_256 instead')
     ap.add_argument('--edge', action='store_true', help='thin outermost layers of unet_256 with their real epilogues')
     args = ap.parse_args()
     torch.manual_seed(0)
+    if args.mx8:
+        return mx8_main(args)
     if args.s1:
         return s1_main(args)
     if args.attn:
@@ -134,6 +138,42 @@ def edge_main(args):
     t = timeit(fn, args.iters)
     byts = B * Hs * Hs * 64 * 2 * 2 + x.numel() * 2
     print(f'L0_fwd_act   M={B*Hs*Hs} N= 64 K=128  {t*1e6:8.1f} us  {byts/t/1e12:6.2f} TB/s (algorithmic bytes)', flush=True)
+
+
+def mx8_main(args):
+    """MX-fp8 3 x 3 conv (csrc/mx8.hip) beside the bf16 patch kernel on the same shapes (config 5: B 8, 512 x 512)."""
+    Bm = args.b if args.b else 8
+    shapes = [('inc2', 512, 64, 0, 64), ('up4c1', 512, 64, 64, 64), ('up4dg', 512, 64, 0, 128), ('d1c2', 256, 128, 0, 128),
+              ('up3c1', 256, 128, 128, 128), ('d2c2', 128, 256, 0, 256), ('d3c2', 64, 512, 0, 512), ('d4c2', 32, 512, 0, 512)]
+    for name, H, C0, C1, N in shapes:
+        if args.only and args.only not in name:
+            continue
+        Cin = C0 + C1
+        in0 = torch.randn(Bm, H, H, C0, device=DEV).to(T)
+        in1 = torch.randn(Bm, H, H, C1, device=DEV).to(T) if C1 else None
+        master = torch.randn(N, 9, Cin, device=DEV) * 0.05
+        out = torch.empty(Bm, H, H, N, device=DEV, dtype=T)
+        P, wsb = K.igemm_query(T, K.GEMM_S1, Bm, H, H, C0, C1, N, [N], ks=3)
+        ws = torch.empty(max(wsb, 16) // 4, device=DEV)
+        part = torch.empty(max(P, K.conv3x3_mx8_num_partials(Bm, H, H)) * 2 * N, device=DEV)
+        w16 = torch.empty(N, K.s1_row_stride(T, 9, Cin), device=DEV, dtype=T)
+        K.pack_rows(master, N, 9, Cin, w16)
+        f16 = lambda: K.igemm(T, K.GEMM_S1, Bm, H, H, in0, in1, w16, N, 1, [K.Seg(N, out0=out, partials=part)], ws, ks=3)
+        q0, s0 = torch.empty(in0.shape, dtype=torch.uint8, device=DEV), torch.empty(Bm, H, H, C0 // 32, dtype=torch.uint8, device=DEV)
+        K.mx8_quantize(in0, q0, s0)
+        q1 = s1 = None
+        if C1:
+            q1, s1 = torch.empty(in1.shape, dtype=torch.uint8, device=DEV), torch.empty(Bm, H, H, C1 // 32, dtype=torch.uint8, device=DEV)
+            K.mx8_quantize(in1, q1, s1)
+        s8, ssc = K.mx8_pack_shapes(N, Cin, False)
+        w8, wsc = torch.empty(s8, dtype=torch.uint8, device=DEV), torch.empty(ssc, dtype=torch.uint8, device=DEV)
+        K.mx8_pack(master, N, Cin, False, w8, wsc)
+        f8 = lambda: K.conv3x3_mx8(Bm, H, H, q0, s0, q1, s1, w8, wsc, N, 1, [K.Seg(N, out0=out, partials=part)])
+        fq = lambda: K.mx8_quantize(in0, q0, s0)
+        t16, t8, tq = timeit(f16, args.iters), timeit(f8, args.iters), timeit(fq, args.iters)
+        fl = 2.0 * Bm * H * H * N * 9 * Cin
+        print(f'{name:8s} M={Bm*H*H:8d} N={N:4d} K={9*Cin:5d}  bf16 {t16*1e6:8.1f} us {fl/t16/1e12:7.1f} TF/s | mx-fp8 {t8*1e6:8.1f} us '
+              f'{fl/t8/1e12:7.1f} TF/s ({t16/t8:4.2f}x) | quantize in0 {tq*1e6:7.1f} us', flush=True)
 
 
 def s1_main(args):
