@@ -356,3 +356,61 @@ extern "C" int adn_depth_prepare(const void* src, int32_t src_type, int32_t plan
   ADN_CHECK_LAUNCH();
   return ADN_OK;
 }
+
+// ---- camera-image preparation (BatvisionV2_Dataset.py:199-210 _load_image after cv2.imread) -------------------------------
+// src u8 [B][H][W][3] BGR (the decoded file) -> out f32 [B][3][S][S] RGB in [0,1]:
+//   cv2.cvtColor(BGR2RGB) -> cv2.resize((S,S)) (INTER_LINEAR, 8-bit path) -> / 255 -> HWC to CHW.
+// The 8-bit INTER_LINEAR path of OpenCV is integer arithmetic, restated here so the result is bit-identical to the host
+// restatement (oracle/frontend_oracle.resize_linear_cv2_u8; "parity unpinned" against OpenCV itself: cv2 is not installed):
+//   source position fx = (dx + 0.5) * (W / S) - 0.5, sx = floor(fx), a = fx - sx; sx < 0 -> (0, a = 0); sx >= W - 1 -> (W - 1, a = 0)
+//   coefficients in 11 bits: c1 = saturate_short(rint(a * 2048)), c0 = 2048 - c1 (cvRound = round half to even)
+//   horizontal pass in int: D = S[sx] * c0 + S[sx + 1] * c1;  vertical pass of the 8-bit specialisation:
+//   dst = (((b0 * (D0 >> 4)) >> 16) + ((b1 * (D1 >> 4)) >> 16) + 2) >> 2.
+__device__ __forceinline__ void cv_lin_coef(int d, double scale, int n, int& s0, int& s1, int& c0, int& c1) {
+  const float fx = (float)((d + 0.5) * scale - 0.5);
+  int sx = (int)floorf(fx);
+  float a = fx - sx;
+  if (sx < 0) {
+    sx = 0;
+    a = 0.f;
+  }
+  if (sx >= n - 1) {
+    sx = n - 1;
+    a = 0.f;
+  }
+  s0 = sx;
+  s1 = sx + 1 < n ? sx + 1 : n - 1;
+  c1 = (int)rintf(a * 2048.f);
+  c0 = 2048 - c1;
+}
+
+__global__ __launch_bounds__(256) void image_prepare_kernel(const uint8_t* src, int B, int H, int W, int So, float* out) {
+  const int64_t n = (int64_t)B * So * So;
+  const double sy = (double)H / So, sx = (double)W / So;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const int x = (int)(e % So), y = (int)((e / So) % So);
+    const int64_t b = e / ((int64_t)So * So);
+    int y0, y1, b0, b1, x0, x1, a0, a1;
+    cv_lin_coef(y, sy, H, y0, y1, b0, b1);
+    cv_lin_coef(x, sx, W, x0, x1, a0, a1);
+    const uint8_t* r0 = src + ((b * H + y0) * W) * 3;
+    const uint8_t* r1 = src + ((b * H + y1) * W) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {                     // c = BGR channel of the source; RGB plane 2 - c of the output
+      const int d0 = r0[x0 * 3 + c] * a0 + r0[x1 * 3 + c] * a1;
+      const int d1 = r1[x0 * 3 + c] * a0 + r1[x1 * 3 + c] * a1;
+      const int v = (((b0 * (d0 >> 4)) >> 16) + ((b1 * (d1 >> 4)) >> 16) + 2) >> 2;
+      out[((b * 3 + (2 - c)) * So + y) * So + x] = (float)v / 255.0f;
+    }
+  }
+}
+
+extern "C" int adn_image_prepare(const void* src_bgr_u8, int32_t B, int32_t H, int32_t W, int32_t S, float* out, void* stream) {
+  ADN_CHECK_ARG(src_bgr_u8 && out && B > 0 && H > 0 && W > 0 && S > 0, "adn_image_prepare: bad arguments");
+  int64_t blocks = adn_cdiv((int64_t)B * S * S, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(image_prepare_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const uint8_t*>(src_bgr_u8), B, H, W, S, out);
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}

@@ -103,6 +103,10 @@ class BatvisionV2Dataset(Dataset):
         image = cv2.imread(image_path)
         if image is None:
             raise RuntimeError(f'Could not load image file {image_path}')
+        if self.frontend == 'raw':
+            # decoded frame as is (uint8 [H,W,3], BGR): colour order, resize, scaling and layout are done for the whole
+            # batch on the device by utils_dataset.GpuImageTransform (frames of one dataset share their size)
+            return torch.from_numpy(image)
         S = self.cfg.dataset.images_size
         image = cv2.resize(cv2.cvtColor(image, cv2.COLOR_BGR2RGB), (S, S)).astype(np.float32) / 255.0
         return torch.from_numpy(image).permute(2, 0, 1)

@@ -120,3 +120,22 @@ class GpuDepthTarget:
         out = torch.empty(raw.shape[0], 1, self.size, self.size, dtype=torch.float32, device=raw.device)
         K.depth_prepare(raw, self.size, self.max_depth, self.max_depth if self.depth_norm else 0.0, out)
         return out
+
+
+class GpuImageTransform:
+    """Batched camera-image preparation on the device (second half): decoded frames uint8
+    [B,H,W,3] in OpenCV's BGR order -> [B,3,S,S] f32 RGB in [0,1], the arithmetic of BatvisionV2_Dataset._load_image
+    (:199-210) after ``cv2.imread``: BGR2RGB, ``cv2.resize`` (8-bit INTER_LINEAR), / 255, HWC -> CHW.  DataLoader workers
+    then only decode files."""
+
+    def __init__(self, size):
+        self.size = size
+
+    def __call__(self, frames):
+        from .. import kernels as K
+        if not frames.is_cuda:
+            raise RuntimeError('GpuImageTransform runs on libadn HIP kernels only (no CPU path)')
+        frames = frames.contiguous()
+        out = torch.empty(frames.shape[0], 3, self.size, self.size, dtype=torch.float32, device=frames.device)
+        K.image_prepare(frames, self.size, out)
+        return out

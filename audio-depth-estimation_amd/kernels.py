@@ -719,6 +719,15 @@ def distill_small(mean_s, mean_t, cent_s, cent_t, feat_stats, feat_channels, pix
     _lib.call('adn_distill_small', C.byref(d), _stream())
 
 
+def image_prepare(src, S, out):
+    """src uint8 [B,H,W,3] BGR (decoded camera frames) -> out f32 [B,3,S,S] RGB in [0,1] (cv2 INTER_LINEAR resize)."""
+    _dev(src, out)
+    if src.dtype != torch.uint8 or src.dim() != 4 or src.shape[-1] != 3:
+        raise TypeError('image_prepare: src must be uint8 [B,H,W,3]')
+    B, H, W, _ = src.shape
+    _lib.call('adn_image_prepare', ptr(src), B, H, W, S, ptr(out), _stream())
+
+
 def depth_prepare(src, S, max_depth, norm, out):
     """Raw depth maps in mm [planes,H,W] (float32 / uint16 / int32) -> metres, cleaned, clipped, nearest-resized."""
     code = {torch.float32: 0, torch.uint16: 1, torch.int32: 2}[src.dtype]

@@ -125,6 +125,9 @@ def _loaders(cfg, args, kind, rank=0, world=1):
             mode = GpuAudioFrontend.bv2_mode(cfg.dataset.audio_format, cfg.dataset.max_depth)
         if kind == 'audio' and 'waveform' not in cfg.dataset.audio_format:
             fe = GpuAudioFrontend(mode, cfg.dataset.images_size)
+        elif kind == 'rgb':                 # raw decoded frames (uint8 BGR) -> [B,3,S,S] RGB in [0,1] on the device
+            from .dataloader.utils_dataset import GpuImageTransform
+            fe = GpuImageTransform(cfg.dataset.images_size)
         workers = args.num_workers
     sampler = torch.utils.data.distributed.DistributedSampler(train, world, rank, shuffle=True) if world > 1 else None
     tl = DataLoader(train, batch_size=args.batch_size, shuffle=sampler is None, sampler=sampler, num_workers=workers,

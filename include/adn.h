@@ -504,6 +504,10 @@ int adn_frontend(const float* wave, int32_t B, int32_t T, int32_t mode, int32_t 
  * (depth_norm: norm = max_depth). */
 int adn_depth_prepare(const void* src, int32_t src_type, int32_t planes, int32_t H, int32_t W, int32_t S,
                       float max_depth, float norm, float* out, void* stream);
+/* Camera-image preparation on the device (BatvisionV2_Dataset.py:199-210 _load_image, everything after cv2.imread):
+ * src u8 [B][H][W][3] BGR -> out f32 [B][3][S][S] RGB in [0,1]: BGR2RGB, cv2.resize((S,S)) with the integer arithmetic
+ * of OpenCV's 8-bit INTER_LINEAR path (11-bit coefficients), / 255, HWC -> CHW. */
+int adn_image_prepare(const void* src_bgr_u8, int32_t B, int32_t H, int32_t W, int32_t S, float* out, void* stream);
 /* transforms.Resize((S,S)) alone (utils_dataset.py:18-20): src f32 [planes][H][W] -> out [planes][S][S]. */
 int adn_resize_bilinear(const float* src, int32_t planes, int32_t H, int32_t W, int32_t S,
                         int32_t antialias, float* out, void* stream);

@@ -163,3 +163,37 @@ def bv2_audio_to_input(wave: np.ndarray, max_depth=30.0, images_size=256,
 def bv1_audio_to_input(wave: np.ndarray, images_size=256, antialias=True) -> np.ndarray:
     """BV1 audio branch: spectrogram(512/64/16) -> resize; no log, no min-max (:76-78)."""
     return resize_bilinear(stft_mag(wave, hop=WIN // 4), images_size, antialias)
+
+
+def resize_linear_cv2_u8(img, S):
+    """cv2.resize(img, (S, S)) for uint8 images, INTER_LINEAR: the integer arithmetic of OpenCV's 8-bit path restated
+    from its published source (modules/imgproc/src/resize.cpp: 11-bit coefficients INTER_RESIZE_COEF_BITS,
+    HResizeLinear in int, the uchar specialisation of VResizeLinear).  img [H,W,C] uint8 -> [S,S,C] uint8.
+    PARITY UNPINNED against OpenCV (cv2 is not installed in this image): pinned by known answers only."""
+    img = np.asarray(img, dtype=np.uint8)
+    H, W = img.shape[:2]
+
+    def coef(n_out, n_in):
+        d = np.arange(n_out)
+        f = ((d + 0.5) * (float(n_in) / n_out) - 0.5).astype(np.float32)
+        s0 = np.floor(f).astype(np.int64)
+        a = (f - s0).astype(np.float32)
+        lo, hi = s0 < 0, s0 >= n_in - 1
+        s0 = np.where(lo, 0, np.where(hi, n_in - 1, s0))
+        a = np.where(lo | hi, np.float32(0), a)
+        c1 = np.rint(a * np.float32(2048)).astype(np.int64)            # cvRound: half to even
+        return s0, np.minimum(s0 + 1, n_in - 1), 2048 - c1, c1
+
+    y0, y1, b0, b1 = coef(S, H)
+    x0, x1, a0, a1 = coef(S, W)
+    src = img.astype(np.int64)
+    rows = src[:, x0] * a0[None, :, None] + src[:, x1] * a1[None, :, None]          # [H,S,C] horizontal pass
+    d0, d1 = rows[y0], rows[y1]
+    v = (((b0[:, None, None] * (d0 >> 4)) >> 16) + ((b1[:, None, None] * (d1 >> 4)) >> 16) + 2) >> 2
+    return v.astype(np.uint8)
+
+
+def load_image_transform(frame_bgr, S):
+    """BatvisionV2_Dataset._load_image (:199-210) after cv2.imread: BGR2RGB, resize, / 255, HWC -> CHW (float32)."""
+    rgb = resize_linear_cv2_u8(np.asarray(frame_bgr)[..., ::-1], S)
+    return np.ascontiguousarray((rgb.astype(np.float32) / np.float32(255.0)).transpose(2, 0, 1))

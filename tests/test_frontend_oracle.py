@@ -101,3 +101,22 @@ def test_uncut_stft_configuration_matches_torch_stft():
     out = fo.bv2_audio_to_input(x, None, 64, 'mel_spectrogram', True)
     assert out.shape == (2, 64, 64) and out.min() >= 0.0 and out.max() <= 1.0
     assert fo.mel_fbanks(n_freqs=201).shape == (201, 32)
+
+
+def test_cv2_linear_resize_restatement_known_answers():
+    """oracle/frontend_oracle.resize_linear_cv2_u8 (OpenCV's 8-bit INTER_LINEAR integer arithmetic, parity unpinned: cv2
+    is absent): identity at equal size, constants stay constant, an exact 2x reduction averages pixel pairs (round half
+    up of the fixed-point sum), borders clamp."""
+    from oracle import frontend_oracle as fo
+    rng = np.random.default_rng(0)
+    sq = rng.integers(0, 256, (16, 16, 3), dtype=np.uint8)
+    np.testing.assert_array_equal(fo.resize_linear_cv2_u8(sq, 16), sq)
+    np.testing.assert_array_equal(fo.resize_linear_cv2_u8(np.full((7, 9, 3), 201, np.uint8), 5), np.full((5, 5, 3), 201, np.uint8))
+    ramp = np.tile((np.arange(16, dtype=np.uint8) * 10)[None, :, None], (16, 1, 1))
+    half = fo.resize_linear_cv2_u8(ramp, 8)                # source position 2 dx + 0.5: mean of pixels 2dx and 2dx + 1
+    np.testing.assert_array_equal(half[0, :, 0], (np.arange(8) * 20 + 5))
+    up = fo.resize_linear_cv2_u8(ramp, 32)                 # 2x enlargement: first / last output columns clamp to the border
+    assert up[0, 0, 0] == 0 and up[0, -1, 0] == 150 and up[0, 2, 0] == 8      # 0.75 * 10 = 7.5 -> 8
+    out = fo.load_image_transform(sq, 16)
+    assert out.shape == (3, 16, 16) and out.dtype == np.float32
+    np.testing.assert_array_equal(out[0], sq[..., 2].astype(np.float32) / np.float32(255))      # R plane = BGR channel 2
