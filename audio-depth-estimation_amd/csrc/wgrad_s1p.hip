@@ -1,0 +1,254 @@
+// Patch-staged weight-gradient kernel of the 3 x 3 stride-1 convolutions (DoubleConv nets; bf16, gfx950).
+//
+//   dW[r][tap][c] = sum over pixels p of  dz[p][r] * in[p + tap][c]
+//
+// Why: the tap-staged kernel (wgrad.hip) lays the 9 taps out as column tiles, so every workgroup stages its own 64-pixel
+// slice of BOTH operands per tap tile: at the 64-channel top level of the nets that is 2.5 KB of LDS-DMA per pixel for
+// 256 B of algorithmic input -- the layers sit at 300-340 TFLOP/s, bound by L2 -> LDS staging.
+// Here a workgroup owns a 64(r) x 64(c) block of the weight gradient for ALL 9 taps and walks 8 x 16 pixel tiles of the
+// images: per tile it stages dz[128 px][64 r] (16 KiB) and the 10 x 18 input patch [180 px][64 c] (22.5 KiB) ONCE and
+// takes the 9 taps as shifted transposed reads of that patch: 308 B of LDS-DMA per pixel and block.
+// The contraction index (pixels) is the slow index of both NHWC operands: fragments are read with ds_read_b64_tr_b16
+// exactly as in wgrad.hip (lane 4q+pp of a 16-lane group supplies pixel row 8 fg + q (+4), 4 channels at 4 pp of a
+// 16-channel block).  LDS rows are 128 bytes (64 channels = four 32-byte granules); granule ^= f(row) with
+// f = ((row >> 1) & 1) | ((row >> 3) & 1) << 1 makes the transposed reads conflict free for ANY row shift (a half wave
+// reads rows {s .. s+3, s+8 .. s+11}: same-parity rows differ in bit 1 or bit 3), applied on the DMA source side.
+// Wave w owns the 16 input channels 16 w .. 16 w + 15 of the block for all 9 taps and all 4 row tiles: 36 accumulator
+// tiles (144 VGPRs); per 32-pixel K-step it reads the 4 dz fragments once and one patch fragment per tap (4 MFMAs each).
+// Pixel tiles are split over the grid into f32 slabs that slab_sum_kernel (wgrad.hip) adds in fixed order (deterministic).
+#include <stdlib.h>
+
+#include <mutex>
+
+#include "adn_common.h"
+
+namespace {
+
+struct SParams {
+  const void* dz;
+  const void* in0;
+  const void* in1;
+  int R, C0, C1;
+  int B, H, W;
+  int nsplit, nrb, ncb;
+  int tiles_total, tpr, tpi;       // pixel tiles in total, per image row of tiles, per image
+  float* out;
+  int64_t out_elems;
+};
+
+__device__ __forceinline__ int swz4(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
+
+__global__ __launch_bounds__(256, 2) void wgrad_s1_patch_kernel(SParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int TH = 8, TW = 16, MW = TW + 2, PPIX = (TH + 2) * MW;     // 180 patch pixels
+  constexpr int DZBUF = 128 * 128;                                      // 128 pixels x 64 channels bf16
+  constexpr int PPIECES = (PPIX * 128 + 1023) / 1024;                   // 23 one-KiB pieces (8 pixels each)
+  constexpr int PBUF = PPIECES * 1024;
+  constexpr int PK = (PPIECES + 3) / 4;                                 // 6 per wave
+  constexpr unsigned OOB = 0x80000000u;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* DZl = smem;                    // [2][DZBUF]
+  char* Pl = smem + 2 * DZBUF;         // [2][PBUF]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // XCD-contiguous order: the (row block, column block) pairs of one pixel split are neighbours on one XCD
+  const int nblk = p.nrb * p.ncb;
+  const int ngrid = nblk * p.nsplit;
+  const int gq = ngrid >> 3, gr = ngrid & 7, gx = blockIdx.x & 7;
+  const int lid = (gx < gr ? gx * (gq + 1) : gr * (gq + 1) + (gx - gr) * gq) + (blockIdx.x >> 3);
+  const int blk = lid % nblk, split = lid / nblk;
+  const int rb = blk / p.ncb, cb = blk - rb * p.ncb;
+  const int r0 = rb * 64, c0 = cb * 64;
+  const int H = p.H, W = p.W, R = p.R;
+  const bool second = c0 >= p.C0;
+  const int Cs = second ? p.C1 : p.C0;
+  const int coff = second ? c0 - p.C0 : c0;
+
+  const int t_begin = (int)(((int64_t)p.tiles_total * split) / p.nsplit);
+  const int t_end = (int)(((int64_t)p.tiles_total * (split + 1)) / p.nsplit);
+
+  // ---- loader geometry (lane constants) ----
+  // piece = 8 LDS rows of 128 bytes; lane l -> row 8 pi + (l >> 3), physical 16-byte chunk l & 7; the lane fetches the
+  // LOGICAL chunk whose swizzled position that is
+  unsigned dvo[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int m = 8 * (wave + 4 * k) + (lane >> 3);                     // tile pixel 0..127
+    const int chunk = ((((lane & 7) >> 1) ^ swz4(m)) << 1) | (lane & 1);
+    dvo[k] = (unsigned)((((m >> 4) * W + (m & 15)) * R + r0 + chunk * 8) * 2);
+  }
+  unsigned pvo[PK];
+  unsigned pmask = 0;          // per piece k: bit 5k + {0: top row, 1: bottom row, 2: left column, 3: right column, 4: beyond the patch}
+  const int bshift = W + 1;
+#pragma unroll
+  for (int k = 0; k < PK; ++k) {
+    const int q = 8 * (wave + 4 * k) + (lane >> 3);
+    const int hr = q / MW, mc = q - hr * MW;
+    const int chunk = ((((lane & 7) >> 1) ^ swz4(q)) << 1) | (lane & 1);
+    pvo[k] = (unsigned)(((hr * W + mc) * Cs + coff + chunk * 8) * 2);
+    const unsigned bits = (hr == 0 ? 1u : 0u) | (hr == TH + 1 ? 2u : 0u) | (mc == 0 ? 4u : 0u) | (mc == MW - 1 ? 8u : 0u) |
+                          ((q >= PPIX || wave + 4 * k >= PPIECES) ? 16u : 0u);
+    pmask |= bits << (5 * k);
+  }
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)p.dz, 0, 0x7ffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(reinterpret_cast<const char*>(second ? p.in1 : p.in0) - (int64_t)bshift * Cs * 2), 0, 0x7ffffff0, 0x00020000);
+
+  // tile t -> (image, tile row, tile column), advanced incrementally
+  int tb = t_begin / p.tpi;
+  int trem = t_begin - tb * p.tpi;
+  int ty = trem / p.tpr, tx = trem - ty * p.tpr;
+
+  auto issue = [&](int buf) {
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int pix0 = (tb * H + oy0) * W + ox0;
+    const unsigned edge = (oy0 == 0 ? 1u : 0u) | (oy0 + TH == H ? 2u : 0u) | (ox0 == 0 ? 4u : 0u) | (ox0 + TW == W ? 8u : 0u) | 16u;
+    char* dd = DZl + buf * DZBUF + wave * 1024;
+    char* pd = Pl + buf * PBUF + wave * 1024;
+    const int dso = pix0 * R * 2, pso = pix0 * Cs * 2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (lptr_t)(dd + k * 4096), 16, dvo[k], dso, 0, 0);
+#pragma unroll
+    for (int k = 0; k < PK; ++k) {
+      if (wave + 4 * k >= PPIECES) continue;
+      const bool inval = ((pmask >> (5 * k)) & edge) != 0;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsp, (lptr_t)(pd + k * 4096), 16, inval ? OOB : pvo[k], pso, 0, 0);
+    }
+  };
+  auto advance = [&]() {
+    if (++tx == p.tpr) {
+      tx = 0;
+      if (++ty * p.tpr == p.tpi) {
+        ty = 0;
+        ++tb;
+      }
+    }
+  };
+
+  f32x4_t acc[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[t][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int fg = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+  auto tr_frag = [&](const char* base, int row_lo, int gran) -> bf16x8_t {
+    const int row_hi = row_lo + 4;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4_t*)(base + row_lo * 128 + ((gran ^ swz4(row_lo)) << 5) + pp * 8));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4_t*)(base + row_hi * 128 + ((gran ^ swz4(row_hi)) << 5) + pp * 8));
+    s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return *reinterpret_cast<bf16x8_t*>(&v);
+  };
+
+  if (t_begin < t_end) issue(0);
+  for (int t = t_begin; t < t_end; ++t) {
+    const int cur = (t - t_begin) & 1;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // own DMA landed, own reads of the previous tile returned
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (t + 1 < t_end) {
+      advance();
+      issue(cur ^ 1);
+    }
+    const char* Db = DZl + cur * DZBUF;
+    const char* Pb = Pl + cur * PBUF;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      // opaque per-K-step copies of the lane's row bases: keeps the ~80 swizzled fragment addresses of the unrolled
+      // body from being hoisted out of the tile loop (they would spill)
+      int mrow = 32 * ks + 8 * fg + qq;                            // dz tile row of this lane's low half
+      int prow = (2 * ks + (fg >> 1)) * MW + ((8 * fg + qq) & 15); // patch pixel of the same output pixel at tap (0, 0)
+      asm volatile("" : "+v"(mrow), "+v"(prow));
+      bf16x8_t af[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = tr_frag(Db, mrow, i);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const bf16x8_t bfr = tr_frag(Pb, prow + (tap / 3) * MW + (tap % 3), wave);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[tap][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr, acc[tap][i], 0, 0, 0);
+      }
+    }
+    // the MFMA intrinsic has no side effects: without a "use" here the IR sink pass moves the tile's MFMAs out of the loop body
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(acc[tap][i]));
+  }
+
+  // ---- epilogue: slab [64 r][9][C] block, accumulator tile (tap, i): rows = r (lane >> 4) * 4 + reg, column = c lane & 15 ----
+  float* out = p.out + (int64_t)split * p.out_elems;
+  const int C = p.C0 + p.C1;
+  const int64_t ldo = (int64_t)9 * C;
+  const int col = c0 + 16 * wave + (lane & 15);
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        out[(int64_t)(r0 + i * 16 + 4 * fg + r) * ldo + tap * C + col] = acc[tap][i][r];
+#endif
+}
+
+bool patch_enabled() {
+  static int on = 1;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    if (const char* e = getenv("ADN_WGRAD_PATCH")) on = atoi(e);
+  });
+  return on != 0;
+}
+
+}  // namespace
+
+// Eligibility + plan: bf16, 3 x 3, one plain source, every channel count a multiple of 64, images tileable by 8 x 16.
+bool adn_wgrad_s1p_plan(const AdnWgradDesc* d, int* nsplit, int64_t* out_elems) {
+  if (!patch_enabled()) return false;
+  if (d->dtype != ADN_BF16 || d->geom != ADN_GEMM_S1 || d->ks != 3) return false;
+  if (d->R1 != 0 || d->R0 % 64 != 0 || d->C0 % 64 != 0 || d->C1 % 64 != 0) return false;
+  if (d->Hs % 8 != 0 || d->Ws % 16 != 0) return false;
+  const int C = d->C0 + d->C1;
+  if (d->c_valid != 0 && d->c_valid != C) return false;
+  const int64_t pix = (int64_t)d->B * d->Hs * d->Ws;
+  if (pix * d->R0 * 2 >= 0x7ff00000ll || pix * (d->C0 > d->C1 ? d->C0 : d->C1) * 2 >= 0x7ff00000ll) return false;
+  const int64_t tiles = pix / 128;
+  const int nblk = (d->R0 / 64) * (C / 64);
+  int ns = 512 / nblk;                        // one resident wave of workgroups (256 CUs x 2)
+  if (ns > tiles / 2) ns = (int)(tiles / 2);
+  if (ns < 1) ns = 1;
+  *nsplit = ns;
+  *out_elems = (int64_t)d->R0 * 9 * C;
+  return true;
+}
+
+int adn_wgrad_s1p_launch(const AdnWgradDesc* d, int nsplit, int64_t out_elems, void* stream) {
+  SParams p;
+  p.dz = d->plain0;
+  p.in0 = d->gath0;
+  p.in1 = d->gath1;
+  p.R = d->R0;
+  p.C0 = d->C0;
+  p.C1 = d->C1;
+  p.B = d->B;
+  p.H = d->Hs;
+  p.W = d->Ws;
+  p.nsplit = nsplit;
+  p.nrb = d->R0 / 64;
+  p.ncb = (d->C0 + d->C1) / 64;
+  p.tpr = d->Ws / 16;
+  p.tpi = (d->Hs / 8) * p.tpr;
+  p.tiles_total = d->B * p.tpi;
+  p.out = nsplit > 1 ? reinterpret_cast<float*>(d->workspace) : d->dw;
+  p.out_elems = out_elems;
+  constexpr int lds = 2 * (128 * 128 + 23 * 1024);
+  ADN_SET_LDS_ONCE(lds, &wgrad_s1_patch_kernel);
+  hipLaunchKernelGGL(wgrad_s1_patch_kernel, dim3(p.nrb * p.ncb * nsplit), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), p);
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}

@@ -55,6 +55,9 @@ S1_SHAPES = [
     (2, 192, 0, 128, 8, 8, 3),      # AdaBins up3.conv2: single source, C = 192
     (2, 96, 0, 64, 16, 16, 3),      # 96 channels: per-lane taps in the forward loader and in wgrad
     (3, 128, 256, 192, 6, 10, 3),   # AdaBins up3.conv1 (N = 192), non power-of-two image (slow wgrad path)
+    (1, 64, 0, 64, 8, 16, 3),       # exactly one 8 x 16 pixel tile (patch kernels: every border at once)
+    (3, 128, 64, 192, 24, 48, 3),   # non power-of-two image of 3 x 3 tiles, N = 192, two sources of different width
+    (2, 256, 0, 64, 16, 32, 3),     # 4 channel blocks of the patch-staged wgrad
     (2, 8, 0, 64, 16, 16, 3),       # thin input: narrow loader, K = 72 padded to the K-step
     (2, 16, 0, 64, 7, 9, 3),        # narrow, odd sizes
     (2, 6, 0, 10, 5, 5, 3),         # generic direct path
