@@ -470,8 +470,16 @@ int wrun(const AdnWgradDesc* d, const WPlan& pl, hipStream_t st) {
 
 }  // namespace
 
+bool adn_wgrad_k4p_plan(const AdnWgradDesc* d, int* nsplit, int64_t* out_elems);   // wgrad_s1p.hip (patch-staged kernels)
+int adn_wgrad_k4p_launch(const AdnWgradDesc* d, int nsplit, int64_t out_elems, void* stream);
+
 int64_t adn_wgrad_k4_workspace_bytes(const AdnWgradDesc* d) {
   if (wvalidate(d) != ADN_OK) return -1;
+  {
+    int ns;
+    int64_t oe;
+    if (adn_wgrad_k4p_plan(d, &ns, &oe)) return ns > 1 ? (int64_t)ns * oe * 4 : 0;
+  }
   WPlan pl;
   make_wplan(d, &pl);
   return pl.slab_bytes;
@@ -480,6 +488,25 @@ int64_t adn_wgrad_k4_workspace_bytes(const AdnWgradDesc* d) {
 int adn_wgrad_k4(const AdnWgradDesc* d, void* stream) {
   int rc = wvalidate(d);
   if (rc != ADN_OK) return rc;
+  {
+    int ns;
+    int64_t oe;
+    if (adn_wgrad_k4p_plan(d, &ns, &oe)) {
+      const int64_t need = ns > 1 ? (int64_t)ns * oe * 4 : 0;
+      ADN_CHECK_ARG(need == 0 || (d->workspace && d->workspace_bytes >= need), "adn_wgrad: workspace too small (%lld < %lld)",
+                    (long long)d->workspace_bytes, (long long)need);
+      rc = adn_wgrad_k4p_launch(d, ns, oe, stream);
+      if (rc != ADN_OK) return rc;
+      if (ns > 1) {
+        int64_t blocks = adn_cdiv(adn_cdiv(oe, 4), 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           reinterpret_cast<const float*>(d->workspace), d->dw, oe, ns);
+        ADN_CHECK_LAUNCH();
+      }
+      return ADN_OK;
+    }
+  }
   WPlan pl;
   make_wplan(d, &pl);
   ADN_CHECK_ARG(pl.slab_bytes == 0 || (d->workspace && d->workspace_bytes >= pl.slab_bytes),

@@ -196,6 +196,190 @@ __global__ __launch_bounds__(256, 2) void wgrad_s1_patch_kernel(SParams p) {
 #endif
 }
 
+// ---- the k4 s2 p1 pair of the U-Net baseline (conv: plain = dZ on the small grid, gathered = layer input on the 2x grid;
+// transposed conv: plain = layer input, gathered = dZ) -----------------------------------------------------------------
+//   dW[r][tap][c] = sum over small-grid pixels (i, j) of  plain[i, j][r] * gath[2i - 1 + ky, 2j - 1 + kx][c]
+// Same idea on 8 x 8 small-grid tiles: a workgroup owns 64(r) x 32(c) x 16 taps and stages, per tile, plain[64 px][64 r]
+// (8 KiB) and the 18 x 18 gathered patch of 32 channels (20.25 KiB) once -- the tap-staged kernel (wgrad_k4.hip) moves
+// 16 KiB + 16 KiB per 64 pixels for every one of its 128-column (tap, c) tiles.  The patch is stored as four planes by
+// (row parity, column parity) of 9 x 9 pixels, 64-byte pixels: tap (ky, kx) of output pixel (y, x) is plane
+// (ky & 1, kx & 1), pixel (y + (ky >> 1), x + (kx >> 1)), so the 4 consecutive output columns a lane group transposes
+// are 4 consecutive LDS rows for every tap.  Granule (16 channels) ^= parity of the plane row: a half wave reads 4 rows
+// of plane row h and 4 of plane row h + 1 -> conflict free.  Wave w: channels 16 (w & 1) .. + 15, kernel rows
+// ky = 2 (w >> 1), 2 (w >> 1) + 1, all kx: 8 taps x 4 row tiles = 32 accumulator tiles.
+struct KParams4 {
+  const void* plain0;
+  const void* plain1;
+  const void* gath0;
+  const void* gath1;
+  int R0, R1, C0, C1;
+  int B, Hs, Ws;
+  int nsplit, nrb, ncb;
+  int tiles_total, tpr, tpi;
+  float* out;
+  int64_t out_elems;
+};
+
+__global__ __launch_bounds__(256, 2) void wgrad_k4_patch_kernel(KParams4 p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int TH = 8, TW = 8, PW = 9, PLANE = PW * PW, PPIX = 4 * PLANE;       // 324 patch pixels of 64 bytes
+  constexpr int DZBUF = 64 * 128;
+  constexpr int PPIECES = (PPIX * 64 + 1023) / 1024;                             // 21 (16 pixels each)
+  constexpr int PBUF = PPIECES * 1024;
+  constexpr int PK = (PPIECES + 3) / 4;                                          // 6 per wave
+  constexpr unsigned OOB = 0x80000000u;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* DZl = smem;                    // [2][DZBUF]
+  char* Pl = smem + 2 * DZBUF;         // [2][PBUF]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nblk = p.nrb * p.ncb;
+  const int ngrid = nblk * p.nsplit;
+  const int gq = ngrid >> 3, gr = ngrid & 7, gx = blockIdx.x & 7;
+  const int lid = (gx < gr ? gx * (gq + 1) : gr * (gq + 1) + (gx - gr) * gq) + (blockIdx.x >> 3);
+  const int blk = lid % nblk, split = lid / nblk;
+  const int rb = blk / p.ncb, cb = blk - rb * p.ncb;
+  const int r0 = rb * 64, c0 = cb * 32;
+  const int Hs = p.Hs, Ws = p.Ws, Hl = 2 * Hs, Wl = 2 * Ws;
+  const bool psecond = r0 >= p.R0;
+  const int Rs = psecond ? p.R1 : p.R0;
+  const int roff = psecond ? r0 - p.R0 : r0;
+  const bool gsecond = c0 >= p.C0;
+  const int Cs = gsecond ? p.C1 : p.C0;
+  const int coff = gsecond ? c0 - p.C0 : c0;
+
+  const int t_begin = (int)(((int64_t)p.tiles_total * split) / p.nsplit);
+  const int t_end = (int)(((int64_t)p.tiles_total * (split + 1)) / p.nsplit);
+
+  unsigned dvo[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int m = 8 * (wave + 4 * k) + (lane >> 3);                     // tile pixel 0..63 (row of 128 bytes)
+    const int chunk = ((((lane & 7) >> 1) ^ swz4(m)) << 1) | (lane & 1);
+    dvo[k] = (unsigned)((((m >> 3) * Ws + (m & 7)) * Rs + roff + chunk * 8) * 2);
+  }
+  unsigned pvo[PK];
+  unsigned pmask = 0;          // per piece: bit 5k + {0: patch row 0, 1: patch row 17, 2: patch column 0, 3: column 17, 4: beyond}
+  const int bshift = Wl + 1;
+#pragma unroll
+  for (int k = 0; k < PK; ++k) {
+    const int q = 16 * (wave + 4 * k) + (lane >> 2);                    // LDS pixel (row of 64 bytes)
+    const int plane = q / PLANE, rem = q - plane * PLANE;
+    const int hr = rem / PW, mc = rem - hr * PW;
+    const int pr = 2 * hr + (plane >> 1), pc = 2 * mc + (plane & 1);
+    const int chunk = ((((lane & 3) >> 1) ^ (hr & 1)) << 1) | (lane & 1);
+    pvo[k] = (unsigned)(((pr * Wl + pc) * Cs + coff + chunk * 8) * 2);
+    const unsigned bits = (pr == 0 ? 1u : 0u) | (pr == 2 * TH + 1 ? 2u : 0u) | (pc == 0 ? 4u : 0u) | (pc == 2 * TW + 1 ? 8u : 0u) |
+                          ((q >= PPIX || wave + 4 * k >= PPIECES) ? 16u : 0u);
+    pmask |= bits << (5 * k);
+  }
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const __amdgpu_buffer_rsrc_t rsd =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(psecond ? p.plain1 : p.plain0), 0, 0x7ffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(reinterpret_cast<const char*>(gsecond ? p.gath1 : p.gath0) - (int64_t)bshift * Cs * 2), 0, 0x7ffffff0, 0x00020000);
+
+  int tb = t_begin / p.tpi;
+  int trem = t_begin - tb * p.tpi;
+  int ty = trem / p.tpr, tx = trem - ty * p.tpr;
+
+  auto issue = [&](int buf) {
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const unsigned edge = (oy0 == 0 ? 1u : 0u) | (oy0 + TH == Hs ? 2u : 0u) | (ox0 == 0 ? 4u : 0u) | (ox0 + TW == Ws ? 8u : 0u) | 16u;
+    char* dd = DZl + buf * DZBUF + wave * 1024;
+    char* pd = Pl + buf * PBUF + wave * 1024;
+    const int dso = ((tb * Hs + oy0) * Ws + ox0) * Rs * 2;
+    const int pso = ((tb * Hl + 2 * oy0) * Wl + 2 * ox0) * Cs * 2;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (lptr_t)(dd + k * 4096), 16, dvo[k], dso, 0, 0);
+#pragma unroll
+    for (int k = 0; k < PK; ++k) {
+      if (wave + 4 * k >= PPIECES) continue;
+      const bool inval = ((pmask >> (5 * k)) & edge) != 0;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsp, (lptr_t)(pd + k * 4096), 16, inval ? OOB : pvo[k], pso, 0, 0);
+    }
+  };
+  auto advance = [&]() {
+    if (++tx == p.tpr) {
+      tx = 0;
+      if (++ty * p.tpr == p.tpi) {
+        ty = 0;
+        ++tb;
+      }
+    }
+  };
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[t][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int fg = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+  const int wct = wave & 1, wky = 2 * (wave >> 1);
+  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+  auto tr_pair = [&](const char* lo_p, const char* hi_p) -> bf16x8_t {
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)lo_p);
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)hi_p);
+    s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return *reinterpret_cast<bf16x8_t*>(&v);
+  };
+
+  if (t_begin < t_end) issue(0);
+  for (int t = t_begin; t < t_end; ++t) {
+    const int cur = (t - t_begin) & 1;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (t + 1 < t_end) {
+      advance();
+      issue(cur ^ 1);
+    }
+    const char* Db = DZl + cur * DZBUF;
+    const char* Pb = Pl + cur * PBUF;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      int mrow = 32 * ks + 8 * fg + qq;              // plain tile row of this lane's low half: pixel (4 ks + fg, qq)
+      int oyl = 4 * ks + fg;
+      asm volatile("" : "+v"(mrow), "+v"(oyl));      // opaque per K-step: no hoisting of the swizzled addresses
+      bf16x8_t af[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        af[i] = tr_pair(Db + mrow * 128 + ((i ^ swz4(mrow)) << 5) + pp * 8, Db + (mrow + 4) * 128 + ((i ^ swz4(mrow + 4)) << 5) + pp * 8);
+#pragma unroll
+      for (int tl = 0; tl < 8; ++tl) {
+        const int dky = tl >> 2, kx = tl & 3;          // ky = wky + dky
+        const int kyh = (wky >> 1);                    // (ky >> 1) is the same for both kernel rows of this wave
+        const int hrow = oyl + kyh;                    // plane row
+        const int row = ((dky << 1) | (kx & 1)) * PLANE + hrow * PW + qq + (kx >> 1);
+        const char* a = Pb + row * 64 + ((wct ^ (hrow & 1)) << 5) + pp * 8;
+        const bf16x8_t bfr = tr_pair(a, a + 4 * 64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[tl][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr, acc[tl][i], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int tl = 0; tl < 8; ++tl)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(acc[tl][i]));
+  }
+
+  float* out = p.out + (int64_t)split * p.out_elems;
+  const int C = p.C0 + p.C1;
+  const int64_t ldo = (int64_t)16 * C;
+  const int col = c0 + 16 * wct + (lane & 15);
+#pragma unroll
+  for (int tl = 0; tl < 8; ++tl) {
+    const int tap = (wky + (tl >> 2)) * 4 + (tl & 3);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[(int64_t)(r0 + i * 16 + 4 * fg + r) * ldo + tap * C + col] = acc[tl][i][r];
+  }
+#endif
+}
+
 bool patch_enabled() {
   static int on = 1;
   static std::once_flag once;
@@ -249,6 +433,56 @@ int adn_wgrad_s1p_launch(const AdnWgradDesc* d, int nsplit, int64_t out_elems, v
   constexpr int lds = 2 * (128 * 128 + 23 * 1024);
   ADN_SET_LDS_ONCE(lds, &wgrad_s1_patch_kernel);
   hipLaunchKernelGGL(wgrad_s1_patch_kernel, dim3(p.nrb * p.ncb * nsplit), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), p);
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}
+
+// k4 s2 p1 pair: bf16, every channel count a multiple of 64 (gathered: 32), small grid tileable by 8 x 8.
+bool adn_wgrad_k4p_plan(const AdnWgradDesc* d, int* nsplit, int64_t* out_elems) {
+  if (!patch_enabled()) return false;
+  if (d->dtype != ADN_BF16 || d->geom != 0) return false;
+  if (d->R0 % 64 != 0 || d->R1 % 64 != 0 || d->C0 % 32 != 0 || d->C1 % 32 != 0) return false;
+  if (d->Hs % 8 != 0 || d->Ws % 8 != 0) return false;
+  const int C = d->C0 + d->C1, R = d->R0 + d->R1;
+  if (d->c_valid != 0 && d->c_valid != C) return false;
+  const int64_t pix = (int64_t)d->B * d->Hs * d->Ws;
+  if (pix * (d->R0 > d->R1 ? d->R0 : d->R1) * 2 >= 0x7ff00000ll || 4 * pix * (d->C0 > d->C1 ? d->C0 : d->C1) * 2 >= 0x7ff00000ll)
+    return false;
+  const int64_t tiles = pix / 64;
+  const int nblk = (R / 64) * (C / 32);
+  if (tiles < 64) return false;               // the innermost levels (<= 4 x 4 images at B = 32): tap-staged split-K kernel
+  int ns = 512 / nblk;
+  if (ns > tiles / 4) ns = (int)(tiles / 4);
+  if (ns < 1) ns = 1;
+  *nsplit = ns;
+  *out_elems = (int64_t)R * 16 * C;
+  return true;
+}
+
+int adn_wgrad_k4p_launch(const AdnWgradDesc* d, int nsplit, int64_t out_elems, void* stream) {
+  KParams4 p;
+  p.plain0 = d->plain0;
+  p.plain1 = d->plain1;
+  p.gath0 = d->gath0;
+  p.gath1 = d->gath1;
+  p.R0 = d->R0;
+  p.R1 = d->R1;
+  p.C0 = d->C0;
+  p.C1 = d->C1;
+  p.B = d->B;
+  p.Hs = d->Hs;
+  p.Ws = d->Ws;
+  p.nsplit = nsplit;
+  p.nrb = (d->R0 + d->R1) / 64;
+  p.ncb = (d->C0 + d->C1) / 32;
+  p.tpr = d->Ws / 8;
+  p.tpi = (d->Hs / 8) * p.tpr;
+  p.tiles_total = d->B * p.tpi;
+  p.out = nsplit > 1 ? reinterpret_cast<float*>(d->workspace) : d->dw;
+  p.out_elems = out_elems;
+  constexpr int lds = 2 * (64 * 128 + 21 * 1024);
+  ADN_SET_LDS_ONCE(lds, &wgrad_k4_patch_kernel);
+  hipLaunchKernelGGL(wgrad_k4_patch_kernel, dim3(p.nrb * p.ncb * nsplit), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), p);
   ADN_CHECK_LAUNCH();
   return ADN_OK;
 }

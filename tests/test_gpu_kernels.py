@@ -157,6 +157,9 @@ def test_conv_dgrad_and_convT_dgrad(dtype, shape):
 WG_SHAPES = [
     (2, 128, 0, 64, 8),      # MFMA: R=128, C=64 (two taps per column tile)
     (2, 128, 128, 128, 4),   # MFMA: two plain sources (convT input = virtual concat)
+    (4, 128, 0, 64, 32),     # patch-staged kernel (bf16): 64 tiles of 8 x 8, R = 128, C = 64 (two channel blocks)
+    (2, 64, 128, 96, 64),    # patch-staged: two plain sources of different width, C = 96 = three 32-channel blocks, every border
+    (16, 64, 0, 32, 16),     # patch-staged: 2 x 2 tiles per image, single 32-channel block
     (2, 8, 0, 6, 4),         # generic
     (1, 4, 4, 1, 8),         # generic, two plain sources, single gathered channel (outermost convT)
 ]
