@@ -27,7 +27,7 @@ namespace {
 //                                               zero-record descriptor (every load dropped, zeros in LDS; wrong results)
 //   ADN_IGEMM_SKIP                              timing-only builds: bit 0 / 1 = the operand's LDS-DMA is not issued at all
 struct Tune {
-  int bm = 0, bn = 0, ns = 0, noa = 0, nob = 0, skip = 0, patch = 1, deep = 1;
+  int bm = 0, bn = 0, ns = 0, noa = 0, nob = 0, skip = 0, patch = 1;
 };
 const Tune& tune() {
   static Tune t;
@@ -40,7 +40,6 @@ const Tune& tune() {
     if (const char* e = getenv("ADN_IGEMM_NOB")) t.nob = atoi(e);
     if (const char* e = getenv("ADN_IGEMM_SKIP")) t.skip = atoi(e);
     if (const char* e = getenv("ADN_IGEMM_PATCH")) t.patch = atoi(e);
-    if (const char* e = getenv("ADN_IGEMM_DEEP")) t.deep = atoi(e);
   });
   return t;
 }
@@ -89,14 +88,12 @@ __device__ __forceinline__ void wait_vmcnt() {
 //   256 x  64, 4x1 waves, 2 stages, 2 workgroups per CU        N = 64: every wave keeps a 64x64 sub-tile
 //   256 x 128, 4x2 waves, 3 stages, 1 workgroup per CU         long K: the DMA of steps s+1 and s+2 stays in
 //             flight across the per-step barrier (counted s_waitcnt vmcnt, raw s_barrier)
-//   128 x 128 / 128 x 64 with DEEP: 4 stages, 1 workgroup per CU   split-K launches of the small-image layers (64-128
-//             workgroups of 8-16 K-steps each: latency bound, three steps of DMA in flight instead of one)
-template <typename T, int BM, int BN, int NWN, int GEOM, bool WIDE, bool DEEP = false>
+template <typename T, int BM, int BN, int NWN, int GEOM, bool WIDE>
 __global__ __launch_bounds__(BM * NWN, 2) void igemm_mfma_kernel(KParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins exist only in the device pass; the host needs the stub only
   constexpr int NTHR = BM * NWN;            // 64 threads per 64 x (BN/NWN) wave tile
   constexpr int NW = NTHR / 64;
-  constexpr int STAGES = DEEP ? 4 : ((BM == 256 && NWN == 2) ? 3 : 2);
+  constexpr int STAGES = (BM == 256 && NWN == 2) ? 3 : 2;
   constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
   constexpr int BK = 8 * EPC;               // elements per K-step (128 bytes)
   constexpr int WN = BN / NWN;              // wave tile columns
@@ -341,8 +338,7 @@ __global__ __launch_bounds__(BM * NWN, 2) void igemm_mfma_kernel(KParams p) {
   const int fq = lane >> 4;
   int cur = 0;
   for (int s = s_begin; s < s_end; ++s) {
-    if (STAGES == 4 && s + 2 < s_end) wait_vmcnt<2 * LOADS>();
-    else if (STAGES >= 3 && s + 1 < s_end) wait_vmcnt<LOADS>();
+    if (STAGES == 3 && s + 1 < s_end) wait_vmcnt<LOADS>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -905,7 +901,6 @@ struct Plan {
   bool mfma;
   bool wide;
   bool patch;       // patch-staged kernel (bf16, wide, unsplit, image 8 x 16 tileable)
-  bool deep;        // 4-stage ring (split-K launches with few workgroups; bf16, wide)
   int wstride;
   int rb;
   int bm;
@@ -936,8 +931,6 @@ bool make_plan(const AdnIgemmDesc* d, Plan* pl) {
   const bool aligned = (pl->wide || narrow_ok) && (d->N % 64 == 0) && (d->seg[0].channels % 64 == 0) &&
                        (d->seg[1].channels % 64 == 0);
   pl->mfma = aligned;
-  pl->deep = false;
-  pl->patch = false;
   if (!aligned) {
     pl->bn = 0;
     pl->nsplit = 1;
@@ -984,7 +977,6 @@ bool make_plan(const AdnIgemmDesc* d, Plan* pl) {
     pl->bm = 128;
     pl->tiles_m = (int)(msmall / 128);
   }
-  pl->deep = ns > 1 && pl->bm == 128 && pl->wide && d->dtype == ADN_BF16 && tn.deep != 0 && (int64_t)pl->tiles_m * pl->tiles_n * pl->phases * ns <= 256;
   pl->rb = reduce_rows(pl->mout, d->N);
   if (ns > 1) {
     pl->partial_rows = adn_cdiv(pl->mout, pl->rb);
@@ -996,14 +988,14 @@ bool make_plan(const AdnIgemmDesc* d, Plan* pl) {
   return true;
 }
 
-template <typename T, int BM_, int BN, int NWN, int GEOM, bool WIDE, bool DEEP = false>
+template <typename T, int BM_, int BN, int NWN, int GEOM, bool WIDE>
 int launch_mfma(const KParams& kp, const Plan& pl, hipStream_t st) {
-  const int stage = (DEEP ? 4 : ((BM_ == 256 && NWN == 2) ? 3 : 2)) * (BM_ + BN) * 128;
+  const int stage = ((BM_ == 256 && NWN == 2) ? 3 : 2) * (BM_ + BN) * 128;
   const int epil = BM_ * (BN + 4) * 4;
   const int lds = stage > epil ? stage : epil;
-  ADN_SET_LDS_ONCE(lds, &igemm_mfma_kernel<T, BM_, BN, NWN, GEOM, WIDE, DEEP>);
+  ADN_SET_LDS_ONCE(lds, &igemm_mfma_kernel<T, BM_, BN, NWN, GEOM, WIDE>);
   dim3 grid(pl.tiles_m * pl.tiles_n * pl.phases, 1, pl.nsplit);
-  hipLaunchKernelGGL((igemm_mfma_kernel<T, BM_, BN, NWN, GEOM, WIDE, DEEP>), grid, dim3(BM_ * NWN), lds, st, kp);
+  hipLaunchKernelGGL((igemm_mfma_kernel<T, BM_, BN, NWN, GEOM, WIDE>), grid, dim3(BM_ * NWN), lds, st, kp);
   return 0;
 }
 
@@ -1012,9 +1004,6 @@ void dispatch_mfma2(const KParams& kp, const Plan& pl, hipStream_t st) {
   if (pl.bm == 256) {
     if (pl.bn == 128) launch_mfma<T, 256, 128, 2, GEOM, WIDE>(kp, pl, st);
     else launch_mfma<T, 256, 64, 1, GEOM, WIDE>(kp, pl, st);
-  } else if (pl.deep) {
-    if (pl.bn == 128) launch_mfma<T, 128, 128, 2, GEOM, WIDE, true>(kp, pl, st);
-    else launch_mfma<T, 128, 64, 2, GEOM, WIDE, true>(kp, pl, st);
   } else {
     if (pl.bn == 128) launch_mfma<T, 128, 128, 2, GEOM, WIDE>(kp, pl, st);
     else launch_mfma<T, 128, 64, 2, GEOM, WIDE>(kp, pl, st);

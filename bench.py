@@ -273,7 +273,7 @@ def main():
         for name in ('r02_pmc_traffic_gemm.json', 'r01_pmc_traffic_gemm.json'):
             try:
                 pm = json.load(open(os.path.join(ROOT, 'profiles', name)))
-                fams = ('igemm_patch_kernel', 'igemm_mfma_kernel') if dom == 'igemm' else ('wgrad_mfma_kernel',)
+                fams = ('igemm_patch_kernel', 'igemm_mfma_kernel') if dom == 'igemm' else ('wgrad_k4_patch_kernel', 'wgrad_mfma_kernel')
                 rows = [v for k, v in pm.items() if k.startswith(fams)]
                 if rows and args.dtype == 'bf16' and B == 32:
                     traffic = sum(r['launches'] * r['hbm_bytes_per_launch'] for r in rows) / sum(r['launches'] for r in rows)
@@ -295,7 +295,7 @@ def main():
                        'parallelism': par},
             'roofline': {'bound': 'mfma',
                          'kernel': {'igemm': 'igemm_patch_kernel + igemm_mfma_kernel (implicit-GEMM family: forward + input gradients)',
-                                    'wgrad': 'wgrad_mfma_kernel'}.get(dom, dom),
+                                    'wgrad': 'wgrad_k4_patch_kernel + wgrad_mfma_kernel (weight gradients)'}.get(dom, dom),
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
                          'traffic': traffic, 'traffic_source': traffic_src, 'launches': launches,
                          'avg_launch_ms': 1e3 * secs / launches,
