@@ -266,3 +266,26 @@ def test_camera_image_preparation_bit_exact(H, W, S):
     np.testing.assert_array_equal(got.cpu().numpy(), want)
     with pytest.raises(RuntimeError):
         GpuImageTransform(S)(torch.from_numpy(frames))
+
+
+def test_binaural_entry_point_on_disk_dataset_with_worker_processes(tmp_path, monkeypatch):
+    """on a REAL dataset the DataLoader workers are forked after the parent has initialised HIP and must
+    never touch the device.  A tiny on-disk BatVision-V2-shaped dataset (wav + npy + csv), ``--num_workers 2``: the
+    workers only read files (``frontend='raw'``), the STFT / mel / resize of the whole batch runs in the parent
+    (GpuAudioFrontend inside the step and the validation forward)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_entrypoints import _fake_bv2
+    from audio_depth_estimation_amd import train_dc
+    cfg = _fake_bv2(str(tmp_path / 'data'), n=6)
+    cfg.dataset.name = 'batvisionv2'
+    cfg.dataset.annotation_file_train = cfg.dataset.annotation_file_val = 'train.csv'
+    cfg.dataset.location_blacklist = None
+    monkeypatch.setattr(train_dc, 'load_config', lambda **kw: cfg)
+    monkeypatch.chdir(tmp_path)
+    model = train_dc.main_binaural(['--batch_size', '2', '--nb_epochs', '2', '--num_workers', '2', '--base_channels', '8',
+                                    '--experiment_name', 'disk', '--save_frequency', '1'])
+    ck = torch.load(os.path.join('checkpoints', 'disk', 'epoch_0002.pth'), map_location='cpu')
+    assert ck['epoch'] == 2 and float(next(iter(ck['optimizer_state_dict']['state'].values()))['step']) == 6   # 6 items / 2
+    assert all(torch.isfinite(v).all() for v in ck['model_state_dict'].values() if v.is_floating_point())
+    assert set(ck['model_state_dict']) == set(model.state_dict())
