@@ -380,11 +380,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_k4_patch_kernel(KParams4 p) {
 #endif
 }
 
+// ADN_WGRAD_PATCH=0 switches the patch-staged kernels off; ADN_WGRAD_WGS = workgroups a launch aims at (default 512 = one
+// resident wave of 2 per CU; every workgroup writes its own f32 slab block, so the slab traffic is proportional to it).
+int g_wgs = 512;
 bool patch_enabled() {
   static int on = 1;
   static std::once_flag once;
   std::call_once(once, [] {
     if (const char* e = getenv("ADN_WGRAD_PATCH")) on = atoi(e);
+    if (const char* e = getenv("ADN_WGRAD_WGS")) g_wgs = atoi(e) > 0 ? atoi(e) : 512;
   });
   return on != 0;
 }
@@ -403,7 +407,7 @@ bool adn_wgrad_s1p_plan(const AdnWgradDesc* d, int* nsplit, int64_t* out_elems) 
   if (pix * d->R0 * 2 >= 0x7ff00000ll || pix * (d->C0 > d->C1 ? d->C0 : d->C1) * 2 >= 0x7ff00000ll) return false;
   const int64_t tiles = pix / 128;
   const int nblk = (d->R0 / 64) * (C / 64);
-  int ns = 512 / nblk;                        // one resident wave of workgroups (256 CUs x 2)
+  int ns = g_wgs / nblk;                      // one resident wave of workgroups (256 CUs x 2)
   if (ns > tiles / 2) ns = (int)(tiles / 2);
   if (ns < 1) ns = 1;
   *nsplit = ns;
@@ -451,7 +455,7 @@ bool adn_wgrad_k4p_plan(const AdnWgradDesc* d, int* nsplit, int64_t* out_elems) 
   const int64_t tiles = pix / 64;
   const int nblk = (R / 64) * (C / 32);
   if (tiles < 64) return false;               // the innermost levels (<= 4 x 4 images at B = 32): tap-staged split-K kernel
-  int ns = 512 / nblk;
+  int ns = g_wgs / nblk;
   if (ns > tiles / 4) ns = (int)(tiles / 4);
   if (ns < 1) ns = 1;
   *nsplit = ns;
