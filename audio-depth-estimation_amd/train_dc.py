@@ -77,6 +77,18 @@ def _common_flags(p, lr, batch):
     p.add_argument('--precision', type=str, default='bf16', choices=['bf16', 'f32', 'mxfp8'])
 
 
+PRECISIONS = {'bf16': torch.bfloat16, 'f32': torch.float32, 'mxfp8': torch.float8_e4m3fn}
+
+
+def _engine_of(model, args):
+    """The model's engine in the precision of ``--precision``.  The precision has to be fixed BEFORE the trainer is built:
+    ``model.engine()`` returns a new engine when ``compute_dtype`` changes, and a trainer built on the previous one would
+    train in the old precision while validation runs the new engine -- two engines re-binding the parameters into their
+    own flat buffers in turn, which resets the optimizer state at every epoch."""
+    model.compute_dtype = PRECISIONS[args.precision]
+    return model.engine()
+
+
 def _dist():
     """(rank, world, local_rank, reducer): torch.distributed from the torchrun environment, RCCL reducer when world > 1."""
     from . import ddp as addp
@@ -161,8 +173,8 @@ def _run(args, cfg, model, trainer, kind, step, forward, exp, ckpt_root='checkpo
          on_epoch=None, dist_info=(0, 1, None, None)):
     rank, world, local, reducer = dist_info
     dev = _device(args, local if world > 1 else None)
-    torch.manual_seed(args.seed)
-    model.compute_dtype = {'bf16': torch.bfloat16, 'f32': torch.float32, 'mxfp8': torch.float8_e4m3fn}[args.precision]
+    model.compute_dtype = PRECISIONS[args.precision]
+    assert trainer.engine is model.engine(), 'build the trainer on _engine_of(model, args)'
     model = model.to(dev).train()
     tl, vl, sampler, fe = _loaders(cfg, args, kind, rank, world)
     ckpt_dir = os.path.join(ckpt_root, exp)
@@ -227,10 +239,11 @@ def main_rgb(argv=None):
     args = p.parse_args(argv)
     cfg = load_config(dataset_name=args.dataset, model_name='unet_baseline', mode='train', experiment_name=args.experiment_name)
     exp = args.experiment_name or f'rgb_depth_{args.dataset}_BS{args.batch_size}_Lr{args.learning_rate}_{args.optimizer}'
+    torch.manual_seed(args.seed)                             # before the model is built (train_rgb_depth.py:168)
     model = create_rgb_depth_model(base_channels=args.base_channels, bilinear=args.bilinear,
                                    output_size=cfg.dataset.images_size, max_depth=cfg.dataset.max_depth)
     di = _dist()
-    trainer = FusedTrainer(model.engine(), 'DepthLoss', 1.0, 0.1, optimizer=args.optimizer, lr=args.learning_rate,
+    trainer = FusedTrainer(_engine_of(model, args), 'DepthLoss', 1.0, 0.1, optimizer=args.optimizer, lr=args.learning_rate,
                            weight_decay=args.weight_decay, clip_norm=None, ddp=di[3])
     step = lambda tr, b: tr.step(b[0], b[1])[0]
     return _run(args, cfg, model, trainer, 'rgb', step, lambda m, b: m(b[0]), exp, dist_info=di)
@@ -258,13 +271,14 @@ def main_binaural(argv=None):
         use_silog = args.use_silog if args.use_silog is not None else (sw != 0.0)
         if not use_silog:
             sw = 0.0
+    torch.manual_seed(args.seed)                             # before the model is built (train_binaural_attention.py:154)
     model = create_binaural_attention_model(base_channels=args.base_channels, bilinear=args.bilinear,
                                             output_size=cfg.dataset.images_size, max_depth=cfg.dataset.max_depth,
                                             attention_levels=args.attention_levels)
     if cfg.dataset.depth_norm:
         raise NotImplementedError('depth_norm with the binaural model (the head already outputs metres, reference :322-337)')
     di = _dist()
-    trainer = FusedTrainer(model.engine(), crit, l1w, sw, args.silog_lambda, max_depth=cfg.dataset.max_depth,
+    trainer = FusedTrainer(_engine_of(model, args), crit, l1w, sw, args.silog_lambda, max_depth=cfg.dataset.max_depth,
                            optimizer=args.optimizer, lr=args.learning_rate, weight_decay=args.weight_decay, clip_norm=None,
                            mask_mode='gt0', ddp=di[3])
     step = lambda tr, b: tr.step(b[0], b[1])[0]
@@ -314,6 +328,7 @@ def main_adabins(argv=None):
     args.scheduler, args.eta_min, args.save_frequency = 'cosine', args.learning_rate * 0.01, 10
     args.num_workers, args.seed, args.device = cfg.mode.num_threads, 42, 'cuda'
     exp = args.experiment_name or f'adabins_distill_{args.dataset}_BS{args.batch_size}_Lr{args.learning_rate}_{args.optimizer}'
+    torch.manual_seed(args.seed)
     model = create_adabins_distillation_model(n_bins=args.n_bins, base_channels=args.base_channels,
                                               output_size=cfg.dataset.images_size, max_depth=cfg.dataset.max_depth)
     if args.freeze_rgb:
@@ -326,7 +341,7 @@ def main_adabins(argv=None):
                                      args.lambda_sparse, args.temperature)
     kind = 'audio' if (cfg.dataset.name == 'batvisionv1' and not args.synthetic) else 'both'
     di = _dist()
-    trainer = AdaBinsTrainer.from_criterion(model.engine(), criterion, optimizer=args.optimizer, lr=args.learning_rate,
+    trainer = AdaBinsTrainer.from_criterion(_engine_of(model, args), criterion, optimizer=args.optimizer, lr=args.learning_rate,
                                             clip_norm=1.0, ddp=di[3])
     def on_epoch(epoch):                                     # criterion.set_epoch(epoch) at every epoch start (:437-438)
         if args.use_adaptive_loss:
@@ -385,6 +400,7 @@ def main_base_residual(argv=None):
     opt = args.optimizer or cfg.mode.optimizer
     args.scheduler, args.save_frequency = 'none', cfg.mode.saving_checkpoints
     args.num_workers, args.seed, args.device = cfg.mode.num_threads, 42, 'cuda'
+    torch.manual_seed(args.seed)
     model = create_base_residual_model(input_channels=2, base_channels=args.base_channels, bilinear=args.bilinear,
                                        output_size=cfg.dataset.images_size, max_depth=cfg.dataset.max_depth)
     if args.use_adaptive_loss:
@@ -397,7 +413,7 @@ def main_base_residual(argv=None):
                                      lambda_sparse=args.lambda_sparse, lowpass_kernel=args.lowpass_kernel,
                                      use_silog=args.use_silog, silog_lambda=args.silog_lambda)
     di = _dist()
-    trainer = BaseResidualTrainer.from_criterion(model.engine(), criterion, optimizer=opt, lr=args.learning_rate,
+    trainer = BaseResidualTrainer.from_criterion(_engine_of(model, args), criterion, optimizer=opt, lr=args.learning_rate,
                                                  weight_decay=0.01 if opt == 'AdamW' else 0.0, clip_norm=1.0, ddp=di[3])
 
     def on_epoch(epoch):

@@ -243,6 +243,42 @@ def test_torchrun_entry_point_two_ranks(tmp_path):
     assert all(torch.isfinite(v).all() for v in ck['model_state_dict'].values() if v.is_floating_point())
 
 
+def test_torchrun_resume_keeps_optimizer_state_and_exchange(tmp_path):
+    """resuming under the reducer.  Two ranks (gloo) train the binaural script for one epoch, a second
+    launch resumes from that checkpoint for a second epoch; the result must be BIT-identical to an uninterrupted
+    two-epoch two-rank run: Adam moments and step count survived the resume (a re-bound flat buffer would zero them) and
+    the gradients are still exchanged afterwards (a reducer left on a stale gradient buffer would leave rank 0 on its own
+    shard's gradients)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ADN_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0',
+               PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
+
+    def launch(exp, extra):
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+               '127.0.0.1', '--master-port', str(_free_port()), '-m', 'audio_depth_estimation_amd.train_binaural_attention',
+               '--synthetic', '8', '--batch_size', '2', '--base_channels', '8', '--save_frequency', '1', '--precision', 'f32',
+               '--experiment_name', exp] + extra
+        r = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        return r.stdout
+
+    launch('resume', ['--nb_epochs', '1'])
+    out = launch('resume', ['--nb_epochs', '2', '--checkpoints', '1'])
+    assert 'Loaded checkpoint from epoch 1' in out
+    launch('straight', ['--nb_epochs', '2'])
+    a = torch.load(os.path.join(tmp_path, 'checkpoints', 'resume', 'epoch_0002.pth'), map_location='cpu')
+    b = torch.load(os.path.join(tmp_path, 'checkpoints', 'straight', 'epoch_0002.pth'), map_location='cpu')
+    sa, sb = a['optimizer_state_dict']['state'], b['optimizer_state_dict']['state']
+    assert a['epoch'] == b['epoch'] == 2 and float(sa[0]['step']) == float(sb[0]['step']) == 4     # 2 steps / epoch / rank
+    for k in a['model_state_dict']:
+        assert torch.equal(a['model_state_dict'][k], b['model_state_dict'][k]), k
+    for i in sa:
+        assert torch.equal(sa[i]['exp_avg'], sb[i]['exp_avg']) and torch.equal(sa[i]['exp_avg_sq'], sb[i]['exp_avg_sq']), i
+    assert float(sa[0]['exp_avg'].abs().max()) > 0
+
+
 # ---- RCCL itself: backend 'nccl' (= RCCL on ROCm), world size 1, in a fresh child process ----------------------------
 def _rccl_worker(port, dtype_name, plan, out):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
