@@ -134,25 +134,25 @@ def gemm_event_pass(trainer, batches, prof_steps):
     return fam
 
 
-def per_step_times(trainer, batches, min_seconds, min_steps, max_steps=4000):
-    """Sustained run: steps until `min_seconds` have passed, one HIP event between consecutive steps; returns the
-    per-step durations (ms) and the wall time.  The events sit on the stream the step runs on."""
+def per_step_times(trainer, batches, n_steps):
+    """Sustained run: ``n_steps`` back-to-back steps, one HIP event between consecutive steps; returns the per-step
+    durations (ms) and the wall time.  The events sit on the stream the step runs on.  The step count is FIXED by the
+    caller (from the all-reduced time of the timed region): under N > 1 every rank must issue the same number of
+    collectives, a per-rank "until t seconds have passed" loop could leave one rank a step ahead and hang the job."""
     evs = [torch.cuda.Event(enable_timing=True)]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     evs[0].record()
-    n = 0
-    while n < max_steps and (n < min_steps or time.perf_counter() - t0 < min_seconds):
-        trainer.step(*batches[n % len(batches)])
+    for n in range(1, n_steps + 1):
+        trainer.step(*batches[(n - 1) % len(batches)])
         e = torch.cuda.Event(enable_timing=True)
         e.record()
         evs.append(e)
-        n += 1
         if n % 64 == 0:
             evs[-1].synchronize()          # keep the host at most 64 steps ahead: wall time then tracks the device
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    return [evs[k].elapsed_time(evs[k + 1]) for k in range(n)], wall
+    return [evs[k].elapsed_time(evs[k + 1]) for k in range(n_steps)], wall
 
 
 def f32_exact_record(device, B, S, rank):
@@ -169,7 +169,7 @@ def f32_exact_record(device, B, S, rank):
     trainer._plan, trainer._plan_after = None, None
     trainer.enable_graph(after_steps=0)
     trainer.step(*batches[0])
-    times, wall = per_step_times(trainer, batches, 1.0, 10, 200)
+    times, wall = per_step_times(trainer, batches, 64)
     times.sort()
     med = times[len(times) // 2]
     flops = sum(v[0] for v in fam.values())
@@ -252,7 +252,8 @@ def main():
     # ---- sustained run behind it: >= 2 s of back-to-back steps, one event per step, median reported
     sustained = None
     if args.sustain_seconds > 0:
-        times, wall = per_step_times(trainer, batches, args.sustain_seconds, 50)
+        n_sust = max(50, min(4000, int(args.sustain_seconds / (elapsed / args.steps)) + 1))    # same on every rank
+        times, wall = per_step_times(trainer, batches, n_sust)
         barrier()
         st = sorted(times)
         med = st[len(st) // 2]
