@@ -27,7 +27,7 @@ namespace {
 //                                               zero-record descriptor (every load dropped, zeros in LDS; wrong results)
 //   ADN_IGEMM_SKIP                              timing-only builds: bit 0 / 1 = the operand's LDS-DMA is not issued at all
 struct Tune {
-  int bm = 0, bn = 0, ns = 0, noa = 0, nob = 0, skip = 0, patch = 1;
+  int bm = 0, bn = 0, ns = 0, noa = 0, nob = 0, skip = 0, patch = 1, tall = 1;
 };
 const Tune& tune() {
   static Tune t;
@@ -40,6 +40,7 @@ const Tune& tune() {
     if (const char* e = getenv("ADN_IGEMM_NOB")) t.nob = atoi(e);
     if (const char* e = getenv("ADN_IGEMM_SKIP")) t.skip = atoi(e);
     if (const char* e = getenv("ADN_IGEMM_PATCH")) t.patch = atoi(e);
+    if (const char* e = getenv("ADN_IGEMM_TALL")) t.tall = atoi(e);
   });
   return t;
 }
@@ -497,11 +498,16 @@ __global__ __launch_bounds__(BM * NWN, 2) void igemm_mfma_kernel(KParams p) {
 // (on the DMA source side), which makes the ds_read_b128 fragment reads conflict free at every alignment (brute-forced).
 // The next patch (half) is loaded into the other patch buffer during the steps of the current one; every step ends in
 // "s_waitcnt vmcnt(0); s_barrier", so it has landed before its first use.
-template <int BN, int GEOM>
+// TALL (64 output columns only): a 16 x 16 pixel tile, the 4 waves stacked along the pixels (64 rows x all 64 columns
+// each).  With the 2 x 2 wave grid a 64-column tile leaves every wave a 64 x 32 sub-tile: 12 ds_read_b128 per 16 MFMAs, and
+// the two waves of a row pair read the same A fragments -- LDS bandwidth, not the matrix pipe, bounds the step (PMC:
+// SQ_WAIT_INST_LDS 4.7x the 128-column variant).  64 x 64 per wave is 8 reads per 16 MFMAs with no shared fragments.
+template <int BN, int GEOM, bool TALL = false>
 __global__ __launch_bounds__(256, 2) void igemm_patch_kernel(KParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef uint16_t T;
-  constexpr int BM = 128, NWN = 2, NTHR = 256, TH = 8, TW = 16;
+  constexpr int TH = TALL ? 16 : 8, TW = 16;
+  constexpr int BM = TH * TW, NWN = TALL ? 1 : 2, NTHR = 256;
   constexpr int WN = BN / NWN, NT = WN / 16, MT = 4;
   constexpr bool S2 = GEOM == ADN_GEMM_S2, S1 = GEOM == ADN_GEMM_S1;
   constexpr int MW = S1 ? TW + 2 : TW + 1;                    // patch columns per plane (S1: 3 x 3 window, 18 columns)
@@ -522,7 +528,7 @@ __global__ __launch_bounds__(256, 2) void igemm_patch_kernel(KParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = TALL ? wave : (wave >> 1), wn = TALL ? 0 : (wave & 1);
   constexpr int NPH = (S2 || S1) ? 1 : 4;
   const int nwg = p.tiles_m * p.tiles_n * NPH;
   const int wg0 = xcd_remap(blockIdx.x, nwg);
@@ -650,7 +656,7 @@ __global__ __launch_bounds__(256, 2) void igemm_patch_kernel(KParams p) {
   //  -- 32 VGPRs that made the 128-column variant spill -- but read in the epilogue if a caller asks for it)
   constexpr bool KEEP_OLD = !(S2 || S1);      // T2 (dgrad of the strided conv) is the accumulating one in the U-Net
   constexpr int NPO = KEEP_OLD ? RPT : 1;
-  const bool pre_on = p.epi == ADN_EPI_BWD;
+  const bool pre_on = !TALL && p.epi == ADN_EPI_BWD;      // (TALL: 8 rows per thread -- the prefetch would cost 64 VGPRs)
   u32x4_t pre_r[RPT], pre_o[NPO], pre_z[RPT];
   if (pre_on) {
     const bool first = e_n0 < p.seg[0].channels;
@@ -901,6 +907,7 @@ struct Plan {
   bool mfma;
   bool wide;
   bool patch;       // patch-staged kernel (bf16, wide, unsplit, image 8 x 16 tileable)
+  bool tall;        // its 16 x 16-pixel, 4 x 1-wave form (64 output columns, T2 / S1, image 16 x 16 tileable)
   int wstride;
   int rb;
   int bm;
@@ -931,6 +938,7 @@ bool make_plan(const AdnIgemmDesc* d, Plan* pl) {
   const bool aligned = (pl->wide || narrow_ok) && (d->N % 64 == 0) && (d->seg[0].channels % 64 == 0) &&
                        (d->seg[1].channels % 64 == 0);
   pl->mfma = aligned;
+  pl->patch = pl->tall = false;
   if (!aligned) {
     pl->bn = 0;
     pl->nsplit = 1;
@@ -973,9 +981,11 @@ bool make_plan(const AdnIgemmDesc* d, Plan* pl) {
   // enough tiles that no split-K is wanted (ADN_IGEMM_PATCH=0 switches it off)
   pl->patch = d->dtype == ADN_BF16 && pl->wide && ns == 1 && (d->geom != ADN_GEMM_S1 || d->ks == 3) && d->Hs % 8 == 0 &&
               d->Ws % 16 == 0 && tn.patch != 0;
+  pl->tall = pl->patch && pl->bn == 64 && d->geom != ADN_GEMM_S2 && d->Hs % 16 == 0 && tn.tall != 0 &&
+             msmall / 256 * pl->tiles_n * pl->phases >= 512;
   if (pl->patch) {
-    pl->bm = 128;
-    pl->tiles_m = (int)(msmall / 128);
+    pl->bm = pl->tall ? 256 : 128;
+    pl->tiles_m = (int)(msmall / pl->bm);
   }
   pl->rb = reduce_rows(pl->mout, d->N);
   if (ns > 1) {
@@ -1015,16 +1025,17 @@ void dispatch_mfma(const KParams& kp, const Plan& pl, hipStream_t st) {
   else dispatch_mfma2<T, GEOM, false>(kp, pl, st);
 }
 
-template <int BN, int GEOM>
+template <int BN, int GEOM, bool TALL = false>
 void launch_patch1(const KParams& kp, const Plan& pl, hipStream_t st) {
   constexpr bool S2 = GEOM == ADN_GEMM_S2, S1 = GEOM == ADN_GEMM_S1;
-  constexpr int ppieces = ((S2 ? 2 * 9 * 17 : (S1 ? 10 * 18 : 9 * 17)) + 15) / 16;
+  constexpr int TH = TALL ? 16 : 8;
+  constexpr int ppieces = ((S2 ? 2 * (TH + 1) * 17 : (S1 ? (TH + 2) * 18 : (TH + 1) * 17)) + 15) / 16;
   constexpr int stage = 2 * ppieces * 1024 + 2 * (S1 ? 3 : 2) * BN * 64;
-  constexpr int epil = 128 * (BN + 4) * 4;
+  constexpr int epil = TH * 16 * (BN + 4) * 4;
   constexpr int lds = stage > epil ? stage : epil;
-  ADN_SET_LDS_ONCE(lds, &igemm_patch_kernel<BN, GEOM>);
+  ADN_SET_LDS_ONCE(lds, &igemm_patch_kernel<BN, GEOM, TALL>);
   dim3 grid(pl.tiles_m * pl.tiles_n * pl.phases, 1, 1);
-  hipLaunchKernelGGL((igemm_patch_kernel<BN, GEOM>), grid, dim3(256), lds, st, kp);
+  hipLaunchKernelGGL((igemm_patch_kernel<BN, GEOM, TALL>), grid, dim3(256), lds, st, kp);
 }
 inline void launch_patch(const KParams& kp, const Plan& pl, int geom, hipStream_t st) {
   if (geom == ADN_GEMM_S2) {
@@ -1032,9 +1043,11 @@ inline void launch_patch(const KParams& kp, const Plan& pl, int geom, hipStream_
     else launch_patch1<64, ADN_GEMM_S2>(kp, pl, st);
   } else if (geom == ADN_GEMM_T2) {
     if (pl.bn == 128) launch_patch1<128, ADN_GEMM_T2>(kp, pl, st);
+    else if (pl.tall) launch_patch1<64, ADN_GEMM_T2, true>(kp, pl, st);
     else launch_patch1<64, ADN_GEMM_T2>(kp, pl, st);
   } else {
     if (pl.bn == 128) launch_patch1<128, ADN_GEMM_S1>(kp, pl, st);
+    else if (pl.tall) launch_patch1<64, ADN_GEMM_S1, true>(kp, pl, st);
     else launch_patch1<64, ADN_GEMM_S1>(kp, pl, st);
   }
 }

@@ -56,6 +56,7 @@ S1_SHAPES = [
     (2, 96, 0, 64, 16, 16, 3),      # 96 channels: per-lane taps in the forward loader and in wgrad
     (3, 128, 256, 192, 6, 10, 3),   # AdaBins up3.conv1 (N = 192), non power-of-two image (slow wgrad path)
     (1, 64, 0, 64, 8, 16, 3),       # exactly one 8 x 16 pixel tile (patch kernels: every border at once)
+    (8, 64, 64, 64, 128, 128, 3),   # 512 tiles of 16 x 16 pixels: the tall 4 x 1-wave patch kernel (N = 64), two sources
     (3, 128, 64, 192, 24, 48, 3),   # non power-of-two image of 3 x 3 tiles, N = 192, two sources of different width
     (2, 256, 0, 64, 16, 32, 3),     # 4 channel blocks of the patch-staged wgrad
     (2, 8, 0, 64, 16, 16, 3),       # thin input: narrow loader, K = 72 padded to the K-step
