@@ -502,7 +502,7 @@ __global__ __launch_bounds__(BM * NWN, 2) void igemm_mfma_kernel(KParams p) {
 // each).  With the 2 x 2 wave grid a 64-column tile leaves every wave a 64 x 32 sub-tile: 12 ds_read_b128 per 16 MFMAs, and
 // the two waves of a row pair read the same A fragments -- LDS bandwidth, not the matrix pipe, bounds the step (PMC:
 // SQ_WAIT_INST_LDS 4.7x the 128-column variant).  64 x 64 per wave is 8 reads per 16 MFMAs with no shared fragments.
-template <int BN, int GEOM, bool TALL = false>
+template <int BN, int GEOM, bool TALL = false, bool PRE = true>
 __global__ __launch_bounds__(256, 2) void igemm_patch_kernel(KParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef uint16_t T;
@@ -656,7 +656,8 @@ __global__ __launch_bounds__(256, 2) void igemm_patch_kernel(KParams p) {
   //  -- 32 VGPRs that made the 128-column variant spill -- but read in the epilogue if a caller asks for it)
   constexpr bool KEEP_OLD = !(S2 || S1);      // T2 (dgrad of the strided conv) is the accumulating one in the U-Net
   constexpr int NPO = KEEP_OLD ? RPT : 1;
-  const bool pre_on = !TALL && p.epi == ADN_EPI_BWD;      // (TALL: 8 rows per thread -- the prefetch would cost 64 VGPRs)
+  // (PRE = false: the TALL forward instantiation -- without the 8 x 2 prefetch registers it keeps 3 waves per SIMD)
+  const bool pre_on = PRE && p.epi == ADN_EPI_BWD;
   u32x4_t pre_r[RPT], pre_o[NPO], pre_z[RPT];
   if (pre_on) {
     const bool first = e_n0 < p.seg[0].channels;
@@ -1025,7 +1026,7 @@ void dispatch_mfma(const KParams& kp, const Plan& pl, hipStream_t st) {
   else dispatch_mfma2<T, GEOM, false>(kp, pl, st);
 }
 
-template <int BN, int GEOM, bool TALL = false>
+template <int BN, int GEOM, bool TALL = false, bool PRE = true>
 void launch_patch1(const KParams& kp, const Plan& pl, hipStream_t st) {
   constexpr bool S2 = GEOM == ADN_GEMM_S2, S1 = GEOM == ADN_GEMM_S1;
   constexpr int TH = TALL ? 16 : 8;
@@ -1033,9 +1034,9 @@ void launch_patch1(const KParams& kp, const Plan& pl, hipStream_t st) {
   constexpr int stage = 2 * ppieces * 1024 + 2 * (S1 ? 3 : 2) * BN * 64;
   constexpr int epil = TH * 16 * (BN + 4) * 4;
   constexpr int lds = stage > epil ? stage : epil;
-  ADN_SET_LDS_ONCE(lds, &igemm_patch_kernel<BN, GEOM, TALL>);
+  ADN_SET_LDS_ONCE(lds, &igemm_patch_kernel<BN, GEOM, TALL, PRE>);
   dim3 grid(pl.tiles_m * pl.tiles_n * pl.phases, 1, 1);
-  hipLaunchKernelGGL((igemm_patch_kernel<BN, GEOM, TALL>), grid, dim3(256), lds, st, kp);
+  hipLaunchKernelGGL((igemm_patch_kernel<BN, GEOM, TALL, PRE>), grid, dim3(256), lds, st, kp);
 }
 inline void launch_patch(const KParams& kp, const Plan& pl, int geom, hipStream_t st) {
   if (geom == ADN_GEMM_S2) {
@@ -1043,11 +1044,13 @@ inline void launch_patch(const KParams& kp, const Plan& pl, int geom, hipStream_
     else launch_patch1<64, ADN_GEMM_S2>(kp, pl, st);
   } else if (geom == ADN_GEMM_T2) {
     if (pl.bn == 128) launch_patch1<128, ADN_GEMM_T2>(kp, pl, st);
-    else if (pl.tall) launch_patch1<64, ADN_GEMM_T2, true>(kp, pl, st);
+    else if (pl.tall && kp.epi == ADN_EPI_BWD) launch_patch1<64, ADN_GEMM_T2, true, true>(kp, pl, st);
+    else if (pl.tall) launch_patch1<64, ADN_GEMM_T2, true, false>(kp, pl, st);
     else launch_patch1<64, ADN_GEMM_T2>(kp, pl, st);
   } else {
     if (pl.bn == 128) launch_patch1<128, ADN_GEMM_S1>(kp, pl, st);
-    else if (pl.tall) launch_patch1<64, ADN_GEMM_S1, true>(kp, pl, st);
+    else if (pl.tall && kp.epi == ADN_EPI_BWD) launch_patch1<64, ADN_GEMM_S1, true, true>(kp, pl, st);
+    else if (pl.tall) launch_patch1<64, ADN_GEMM_S1, true, false>(kp, pl, st);
     else launch_patch1<64, ADN_GEMM_S1>(kp, pl, st);
   }
 }
