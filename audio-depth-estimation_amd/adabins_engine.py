@@ -205,9 +205,11 @@ class AdaBinsEngine(DCEngine):
         if self._shape_enter(key):
             return
         m = self.module
-        if H != m.output_size or W != m.output_size:
-            raise NotImplementedError(f'input {H}x{W} != output_size {m.output_size}: the nearest-neighbour resize of the '
-                                      'logits (reference :194-196) is not on the libadn path')
+        # output_size != input size: the reference resizes logits and residual with mode='nearest' before the per-pixel
+        # softmax expectation / tanh / clamp (:196-198, 334-337, 383-386); per-pixel maps commute with a nearest resize, so
+        # the forward outputs are computed at the input resolution and resized at the end (_outputs).  The fused TRAINING
+        # step exists for output_size == input size only (what train_adabins_distillation.py uses); it raises otherwise.
+        self.resize_to = m.output_size if (H != m.output_size or W != m.output_size) else None
         self.B, self.dev = B, dev
         self._scratch = {}
         self.epc = 8 if self.dtype == torch.bfloat16 else 4
@@ -298,9 +300,11 @@ class AdaBinsEngine(DCEngine):
         logits = torch.empty(B, lg.C, lg.H, lg.W, dtype=torch.float32, device=self.dev)
         K.nhwc_to_nchw(lg.data, logits)
         shp = (B, 1, lg.H, lg.W)
+        base, resid, final = br.base.view(shp).clone(), br.head.result.view(shp).clone(), br.final.clone()
+        if self.resize_to is not None:
+            logits, base, resid, final = [K.resize_nearest(t, self.resize_to) for t in (logits, base, resid, final)]
         return {'features': feats, 'bin_centers': br.centers.clone(), 'bin_widths': br.widths.clone(), 'bin_logits': logits,
-                'base_depth': br.base.view(shp).clone(), 'residual': br.head.result.view(shp).clone(),
-                'final_depth': br.final.clone()}
+                'base_depth': base, 'residual': resid, 'final_depth': final}
 
     # ------------------------------------------------------------------ backward of the student
     def backward_student(self, dbase, dres, dmean, dcent_extra):
@@ -434,6 +438,9 @@ class AdaBinsTrainer(GraphedStep):
         eng = self.engine
         m = eng.module
         eng._prepare_branches(audio.shape[0], audio.shape[2], audio.shape[3], audio.device)
+        if eng.resize_to is not None:
+            raise NotImplementedError(f'AdaBinsTrainer: input {audio.shape[2]}x{audio.shape[3]} != output_size {m.output_size}; the '
+                                      'fused distillation step is built for output_size == input size (forward() supports both)')
         if not self._ready:
             self._setup(audio.device)
         st, te = eng.branches['audio'], eng.branches['rgb']

@@ -414,3 +414,29 @@ extern "C" int adn_image_prepare(const void* src_bgr_u8, int32_t B, int32_t H, i
   ADN_CHECK_LAUNCH();
   return ADN_OK;
 }
+
+// ---- F.interpolate(mode='nearest') to (S, S): src f32 [planes][H][W] -> out [planes][S][S], source index
+// min(floor(dst * in / out), in - 1) (torch's legacy 'nearest' = OpenCV's INTER_NEAREST rule).  Used by the AdaBins model
+// for its outputs when output_size != input size (adabins_distillation_model.py:196-198, 334-337, 383-386).
+__global__ __launch_bounds__(256) void resize_nearest_kernel(const float* src, int64_t planes, int H, int W, int So, float* out) {
+  const int64_t n = planes * So * So;
+  const float sy = (float)H / So, sx = (float)W / So;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const int x = (int)(e % So), y = (int)((e / So) % So);
+    const int64_t pl = e / ((int64_t)So * So);
+    int iy = (int)floorf(y * sy), ix = (int)floorf(x * sx);
+    iy = iy < H - 1 ? iy : H - 1;
+    ix = ix < W - 1 ? ix : W - 1;
+    out[e] = src[(pl * H + iy) * W + ix];
+  }
+}
+
+extern "C" int adn_resize_nearest(const float* src, int64_t planes, int32_t H, int32_t W, int32_t S, float* out, void* stream) {
+  ADN_CHECK_ARG(src && out && planes > 0 && H > 0 && W > 0 && S > 0, "adn_resize_nearest: bad arguments");
+  int64_t blocks = adn_cdiv(planes * S * S, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(resize_nearest_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src,
+                     planes, H, W, S, out);
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}

@@ -719,6 +719,16 @@ def distill_small(mean_s, mean_t, cent_s, cent_t, feat_stats, feat_channels, pix
     _lib.call('adn_distill_small', C.byref(d), _stream())
 
 
+def resize_nearest(src, S):
+    """src f32 [..., H, W] -> new tensor [..., S, S], F.interpolate(mode='nearest')."""
+    _dev(src)
+    src = src.contiguous()
+    out = torch.empty(src.shape[:-2] + (S, S), dtype=torch.float32, device=src.device)
+    planes = src.numel() // (src.shape[-1] * src.shape[-2])
+    _lib.call('adn_resize_nearest', ptr(src), planes, src.shape[-2], src.shape[-1], S, ptr(out), _stream())
+    return out
+
+
 def image_prepare(src, S, out):
     """src uint8 [B,H,W,3] BGR (decoded camera frames) -> out f32 [B,3,S,S] RGB in [0,1] (cv2 INTER_LINEAR resize)."""
     _dev(src, out)

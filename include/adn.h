@@ -508,6 +508,10 @@ int adn_depth_prepare(const void* src, int32_t src_type, int32_t planes, int32_t
  * src u8 [B][H][W][3] BGR -> out f32 [B][3][S][S] RGB in [0,1]: BGR2RGB, cv2.resize((S,S)) with the integer arithmetic
  * of OpenCV's 8-bit INTER_LINEAR path (11-bit coefficients), / 255, HWC -> CHW. */
 int adn_image_prepare(const void* src_bgr_u8, int32_t B, int32_t H, int32_t W, int32_t S, float* out, void* stream);
+/* F.interpolate(..., size=(S,S), mode='nearest') of f32 maps [planes][H][W] (source index floor(dst * in / out)): the
+ * AdaBins model's logits / residual when output_size != input size (adabins_distillation_model.py:196-198, 334-337, 383-386;
+ * softmax expectation, tanh and clamp are per-pixel, so resizing their results is the same as resizing their inputs). */
+int adn_resize_nearest(const float* src, int64_t planes, int32_t H, int32_t W, int32_t S, float* out, void* stream);
 /* transforms.Resize((S,S)) alone (utils_dataset.py:18-20): src f32 [planes][H][W] -> out [planes][S][S]. */
 int adn_resize_bilinear(const float* src, int32_t planes, int32_t H, int32_t W, int32_t S,
                         int32_t antialias, float* out, void* stream);

@@ -192,7 +192,7 @@ def bin_predictor(sd, prefix, x5, max_depth, drop_mask=None, drop_p=0.1):
     return (edges[:, :-1] + edges[:, 1:]) / 2, widths
 
 
-def adabins_branch(sd, enc, pred, dec, x, max_depth, training, new_stats, drop_mask=None):
+def adabins_branch(sd, enc, pred, dec, x, max_depth, training, new_stats, drop_mask=None, output_size=None):
     """forward_audio / forward_rgb (:301-399).  The reference runs the decoder twice on identical inputs (once inside
     the decoder module, once for the residual head); the second pass reproduces the first one's activations, so
     it is evaluated once here and only its side effect -- a second BatchNorm running-stat update in train mode -- is
@@ -210,24 +210,30 @@ def adabins_branch(sd, enc, pred, dec, x, max_depth, training, new_stats, drop_m
             batch = (once - (1 - BN_MOMENTUM) * prev) / BN_MOMENTUM
             new_stats[k] = (1 - BN_MOMENTUM) * once + BN_MOMENTUM * batch
     logits = F.conv2d(d, sd[dec + '.class_head.weight'], sd[dec + '.class_head.bias'])
+    resid_raw = F.conv2d(d, sd['residual_head.weight'], sd['residual_head.bias'])
+    if output_size is not None and logits.shape[-1] != output_size:           # :196-198, :334-337, :383-386
+        logits = F.interpolate(logits, size=(output_size, output_size), mode='nearest')
+        resid_raw = F.interpolate(resid_raw, size=(output_size, output_size), mode='nearest')
     probs = torch.softmax(logits, 1)
     base = (probs * centers[:, :, None, None]).sum(1, keepdim=True)
-    residual = torch.tanh(F.conv2d(d, sd['residual_head.weight'], sd['residual_head.bias'])) * (max_depth * 0.05)
+    residual = torch.tanh(resid_raw) * (max_depth * 0.05)
     final = torch.clamp(base + residual, 0, max_depth)
     return {'features': {f'x{i + 1}': feats[i] for i in range(5)}, 'bin_centers': centers, 'bin_widths': widths,
             'bin_logits': logits, 'base_depth': base, 'residual': residual, 'final_depth': final}
 
 
-def adabins_forward(sd, audio, rgb=None, max_depth=30.0, training=True, drop_mask_audio=None, drop_mask_rgb=None):
-    """AdaBinsDistillationModel.forward (:401-426) for output_size == input size; teacher under no_grad."""
+def adabins_forward(sd, audio, rgb=None, max_depth=30.0, training=True, drop_mask_audio=None, drop_mask_rgb=None,
+                    output_size=None):
+    """AdaBinsDistillationModel.forward (:401-426); teacher under no_grad.  ``output_size``: the nearest resize of the
+    logits / raw residual when it differs from the input size."""
     new_stats = {}
     a = adabins_branch(sd, 'audio_encoder', 'audio_bin_predictor', 'audio_decoder', audio, max_depth, training,
-                       new_stats, drop_mask_audio)
+                       new_stats, drop_mask_audio, output_size)
     r = None
     if rgb is not None:
         with torch.no_grad():
             r = adabins_branch(sd, 'rgb_encoder', 'rgb_bin_predictor', 'rgb_decoder', rgb, max_depth, training,
-                               new_stats, drop_mask_rgb)
+                               new_stats, drop_mask_rgb, output_size)
     return {'audio': a, 'rgb': r}, new_stats
 
 
