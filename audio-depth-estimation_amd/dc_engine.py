@@ -151,7 +151,9 @@ class ConvBNReLU(Op):
         # MX-fp8 variant of this layer (engine in fp8 mode): 3 x 3, every channel count a multiple of 64, image tileable
         # by 8 x 16 pixels; other layers (the thin first conv, 1 x 1 convs) stay on the bf16 kernels
         self.mx8 = bool(eng.mx8 and self.ks == 3 and not self.padded and self.cin_real == cin and self.c0 % 64 == 0 and
-                        self.c1 % 64 == 0 and N % 64 == 0 and H % 8 == 0 and W % 16 == 0)
+                        self.c1 % 64 == 0 and N % 64 == 0 and H % 8 == 0 and W % 16 == 0 and
+                        o.pair_data is None and all(s_.pair_data is None for s_ in self.srcs) and
+                        o.data.shape[0] == B and all(s_.data.shape[0] == B for s_ in self.srcs))
         u8 = dict(dtype=torch.uint8, device=dev)
         if self.mx8:
             s8, ssc = K.mx8_pack_shapes(N, cin, False)

@@ -174,3 +174,53 @@ def test_rgb512_mxfp8_training_determinism_and_descent():
     print('loss mxfp8', [round(v, 4) for v in l8], 'bf16', [round(v, 4) for v in l16])
     assert all(np.isfinite(l8)) and l8[-1] < 0.7 * l8[0]                          # it trains
     assert abs(l8[-1] - l16[-1]) <= 0.15 * l16[0]                                 # and tracks the bf16 run
+
+
+@pytest.mark.parametrize('kind', ['binaural', 'adabins', 'baseres'])
+def test_mxfp8_on_the_other_doubleconv_nets(kind):
+    """compute_dtype = float8_e4m3fn on the sibling families (64 x 64, B = 2): the engine picks fp8 for the eligible 3 x 3
+    convs (none of the stacked [left; right] encoder convs of the binaural net: their operands are halves of one buffer),
+    three fused steps stay finite and the loss tracks the bf16 run of the same seed within 5 %."""
+    from audio_depth_estimation_amd.engine import FusedTrainer
+    g = torch.Generator().manual_seed(11)
+    Sx, B = 64, 2
+    audio, rgb = torch.rand(B, 2, Sx, Sx, generator=g).to(DEV), torch.rand(B, 3, Sx, Sx, generator=g).to(DEV)
+    gt = (30 * torch.rand(B, 1, Sx, Sx, generator=g)).to(DEV)
+    gt[gt < 3] = 0
+    losses, n_mx = {}, 0
+    for name, dt in (('bf16', torch.bfloat16), ('mxfp8', torch.float8_e4m3fn)):
+        torch.manual_seed(0)
+        if kind == 'binaural':
+            from audio_depth_estimation_amd.models.binaural_attention_model import BinauralAttentionDepthNet
+            m = BinauralAttentionDepthNet(64, True, Sx, 30.0)
+            m.compute_dtype = dt
+            m = m.to(DEV).train()
+            tr = FusedTrainer(m.engine(), 'L1', optimizer='AdamW', lr=1e-4, weight_decay=0.01, clip_norm=None, mask_mode='gt0')
+            step = lambda: tr.step(audio, gt)[0]
+        elif kind == 'adabins':
+            from audio_depth_estimation_amd.adabins_engine import AdaBinsTrainer
+            from audio_depth_estimation_amd.models.adabins_distillation_model import AdaBinsDistillationModel
+            m = AdaBinsDistillationModel(128, 64, Sx, 30.0)
+            m.compute_dtype = dt
+            m = m.to(DEV).train()
+            tr = AdaBinsTrainer(m.engine(), lr=1e-4)
+            step = lambda: tr.step(audio, rgb, gt)[0]
+        else:
+            from audio_depth_estimation_amd.base_residual_engine import BaseResidualTrainer
+            from audio_depth_estimation_amd.models.base_residual_model import BaseResidualDepthNet
+            m = BaseResidualDepthNet(2, 64, True, Sx, 30.0)
+            m.compute_dtype = dt
+            m = m.to(DEV).train()
+            tr = BaseResidualTrainer(m.engine(), use_silog=True, lr=1e-4)
+            step = lambda: tr.step(audio, gt)[0]
+        ls = [float(step()) for _ in range(3)]
+        assert all(np.isfinite(ls)), (name, ls)
+        losses[name] = ls
+        if name == 'mxfp8':
+            eng = m.engine()
+            assert eng.mx8 and eng.dtype == torch.bfloat16
+            n_mx = sum(1 for op in eng.ops if getattr(op, 'mx8', False))
+        del m, tr
+    print(kind, 'fp8 convs:', n_mx, losses)
+    assert n_mx >= 4
+    assert abs(losses['mxfp8'][-1] - losses['bf16'][-1]) <= 0.05 * abs(losses['bf16'][-1])
