@@ -126,18 +126,23 @@ struct MxParams {
 
 __device__ __forceinline__ void wait_all() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
 
-template <int BN>
+// TALL (64 output columns): 16 x 16-pixel tile, the 4 waves stacked along the pixels (64 x 64 each) instead of 2 x 2 waves
+// of 64 x 32 -- 8 instead of 12 fragment reads per 16 MFMAs and no fragment read twice (see igemm_patch_kernel).
+template <int BN, bool TALL = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_mx8_kernel(MxParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef uint16_t T;                                       // output / epilogue element type: bf16
-  constexpr int BM = 128, NWN = 2, NTHR = 256, TH = 8, TW = 16;
+  constexpr int TH = TALL ? 16 : 8, TW = 16;
+  constexpr int BM = TH * TW, NWN = TALL ? 1 : 2, NTHR = 256;
   constexpr int WN = BN / NWN, NT = WN / 16, MT = 4;
-  constexpr int MW = TW + 2, SEG_PIX = (TH + 2) * MW;       // 18 x 10 = 180 patch pixels of 64 bytes
+  constexpr int MW = TW + 2, SEG_PIX = (TH + 2) * MW;       // 18 x 10 = 180 (tall: 18 x 18 = 324) patch pixels of 64 bytes
   constexpr int SEG_STEPS = 5;                              // tap pairs (0,1) (2,3) (4,5) (6,7) (8, zero tap)
-  constexpr int PPIECES = (SEG_PIX + 15) / 16;              // 12 one-KiB pieces
-  constexpr int PK = (PPIECES + 3) / 4;                     // 3 per wave
+  constexpr int PPIECES = (SEG_PIX + 15) / 16;              // 12 (21) one-KiB pieces
+  constexpr int PK = (PPIECES + 3) / 4;                     // 3 (6) per wave
   constexpr int PBUF = PPIECES * 1024;
-  constexpr int ASBUF = 3 * 256;                            // 192 pixels x one dword (2 scale bytes, zero-extended)
+  constexpr int SPIECES = (SEG_PIX + 63) / 64;              // scale-patch DMA instructions of 64 pixels: 3 (6)
+  constexpr int SK = (SPIECES + 3) / 4;                     // per wave: 1 (2)
+  constexpr int ASBUF = SPIECES * 256;                      // one dword per pixel (2 scale bytes, zero-extended)
   constexpr int BPT = BN / 16;                              // weight pieces per tap
   constexpr int BK_ = 2 * BPT / 4;                          // weight pieces per wave and step
   constexpr int BBUF = 2 * BN * 64;
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mx8_kernel(MxParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = TALL ? wave : (wave >> 1), wn = TALL ? 0 : (wave & 1);
   const int nwg = p.tiles_m * p.tiles_n;
   const int wg = xcd_remap8(blockIdx.x, nwg);
   const int tile_n = wg % p.tiles_n;
@@ -176,15 +181,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mx8_kernel(MxParams p) {
     ppix[k] = (unsigned)((tb * H + iy) * W + ix + bshift);
     pmask |= (ok ? 1u : 0u) << k;
   }
-  // scale patch: waves 0..2, lane -> LDS pixel 64 wave + lane (2 bytes)
-  unsigned spix = 0;
-  bool sok = false;
-  if (wave < 3) {
-    const int q = 64 * wave + lane;
+  // scale patch: DMA instruction wave + 4k covers LDS pixels 64 (wave + 4k) .. + 63, lane -> its pixel (2 bytes)
+  unsigned spix[SK];
+  unsigned smask = 0;
+#pragma unroll
+  for (int k = 0; k < SK; ++k) {
+    const int q = 64 * (wave + 4 * k) + lane;
     const int hr = q / MW, m = q - hr * MW;
     const int iy = oy0 + hr - 1, ix = ox0 + m - 1;
-    sok = (unsigned)ix < (unsigned)W && (unsigned)iy < (unsigned)H && q < SEG_PIX;
-    spix = (unsigned)((tb * H + iy) * W + ix + bshift);
+    const bool ok = (unsigned)ix < (unsigned)W && (unsigned)iy < (unsigned)H && q < SEG_PIX;
+    spix[k] = (unsigned)((tb * H + iy) * W + ix + bshift);
+    smask |= (ok ? 1u : 0u) << k;
   }
   unsigned bvo[BK_];
   const int ktot = 10 * Cin;
@@ -222,18 +229,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mx8_kernel(MxParams p) {
     char* dst = Pl + (sg & 1) * PBUF + wave * 1024;
 #pragma unroll
     for (int k = 0; k < PK; ++k) {
-      if (k != ss) continue;
+      if (k % SEG_STEPS != ss) continue;
+      if (wave + 4 * k >= PPIECES) continue;
       const bool ok = (pmask >> k) & 1u;
       const unsigned lc16 = (unsigned)(((lane & 3) ^ (((lane >> 4) & 1) << 1)) << 4);
       const unsigned vo = ok ? ppix[k] * (unsigned)Cs + lc16 : OOB;
       if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lptr_t)(dst + k * 4096), 16, vo, coff, 0, 0);
       else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lptr_t)(dst + k * 4096), 16, vo, coff, 0, 0);
     }
-    if (ss == 3 && wave < 3) {
-      const unsigned vo = sok ? spix * (unsigned)(Cs >> 5) : OOB;
-      char* sd = ASl + (sg & 1) * ASBUF + wave * 256;
-      if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rq1, (lptr_t)sd, 2, vo, coff >> 5, 0, 0);
-      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rq0, (lptr_t)sd, 2, vo, coff >> 5, 0, 0);
+    if (ss == 3) {
+#pragma unroll
+      for (int k = 0; k < SK; ++k) {
+        if (wave + 4 * k >= SPIECES) continue;
+        const unsigned vo = ((smask >> k) & 1u) ? spix[k] * (unsigned)(Cs >> 5) : OOB;
+        char* sd = ASl + (sg & 1) * ASBUF + (wave + 4 * k) * 256;
+        if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rq1, (lptr_t)sd, 2, vo, coff >> 5, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rq0, (lptr_t)sd, 2, vo, coff >> 5, 0, 0);
+      }
     }
   };
   auto issue_b = [&](int s) {
@@ -254,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mx8_kernel(MxParams p) {
 
   // ---- prologue: the whole first patch + scales, weights of step 0 ----
 #pragma unroll
-  for (int ss = 0; ss < 4; ++ss) issue_patch(0, ss);
+  for (int ss = 0; ss < SEG_STEPS; ++ss) issue_patch(0, ss);
   issue_b(0);
 
   const int frow = lane & 15, fq = lane >> 4;
@@ -393,13 +405,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mx8_kernel(MxParams p) {
 #endif
 }
 
-template <int BN>
+template <int BN, bool TALL = false>
 void launch_mx8(const MxParams& kp, hipStream_t st) {
-  constexpr int stage = 2 * 12 * 1024 + 2 * (2 * BN * 64) + 2 * 768 + 2 * BN * 4;
-  constexpr int epil = 128 * (BN + 4) * 4;
+  constexpr int TH = TALL ? 16 : 8;
+  constexpr int segpix = (TH + 2) * 18;
+  constexpr int stage = 2 * ((segpix + 15) / 16) * 1024 + 2 * (2 * BN * 64) + 2 * ((segpix + 63) / 64) * 256 + 2 * BN * 4;
+  constexpr int epil = TH * 16 * (BN + 4) * 4;
   constexpr int lds = stage > epil ? stage : epil;
-  ADN_SET_LDS_ONCE(lds, &conv3x3_mx8_kernel<BN>);
-  hipLaunchKernelGGL((conv3x3_mx8_kernel<BN>), dim3(kp.tiles_m * kp.tiles_n), dim3(256), lds, st, kp);
+  ADN_SET_LDS_ONCE(lds, &conv3x3_mx8_kernel<BN, TALL>);
+  hipLaunchKernelGGL((conv3x3_mx8_kernel<BN, TALL>), dim3(kp.tiles_m * kp.tiles_n), dim3(256), lds, st, kp);
+}
+
+// rows per workgroup: 256 (tall form) for 64-column layers whose images tile by 16 x 16 and still fill the chip
+int mx8_rows(const AdnMx8ConvDesc* d) {
+  const bool tall = d->N % 128 != 0 && d->H % 16 == 0 && (int64_t)d->B * d->H * d->W / 256 * (d->N / 64) >= 512;
+  return tall ? 256 : 128;
 }
 
 int validate(const AdnMx8ConvDesc* d) {
@@ -458,7 +478,7 @@ extern "C" int adn_mx8_pack(const float* master, int32_t X, int32_t Y, int32_t t
 
 extern "C" int64_t adn_conv3x3_mx8_num_partials(const AdnMx8ConvDesc* d) {
   if (validate(d) != ADN_OK) return -1;
-  return (int64_t)d->B * d->H * d->W / 128;
+  return (int64_t)d->B * d->H * d->W / mx8_rows(d);
 }
 
 extern "C" int adn_conv3x3_mx8(const AdnMx8ConvDesc* d, void* stream) {
@@ -481,10 +501,12 @@ extern "C" int adn_conv3x3_mx8(const AdnMx8ConvDesc* d, void* stream) {
   kp.seg[0] = d->seg[0];
   kp.seg[1] = d->seg[1];
   const int bn = d->N % 128 == 0 ? 128 : 64;
-  kp.tiles_m = (int)((int64_t)d->B * d->H * d->W / 128);
+  const int rows = mx8_rows(d);
+  kp.tiles_m = (int)((int64_t)d->B * d->H * d->W / rows);
   kp.tiles_n = d->N / bn;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (bn == 128) launch_mx8<128>(kp, st);
+  else if (rows == 256) launch_mx8<64, true>(kp, st);
   else launch_mx8<64>(kp, st);
   ADN_CHECK_LAUNCH();
   return ADN_OK;

@@ -168,14 +168,14 @@ class ConvBNReLU(Op):
                     s_.q8, s_.q8s = torch.empty(B, s_.H, s_.W, s_.C, **u8), torch.empty(B, s_.H, s_.W, s_.C // 32, **u8)
         self.P, ws1 = K.igemm_query(T, GEMM_S1, B, H, W, self.c0, self.c1, N, [N], ks=self.ks)
         if self.mx8:
-            self.P, ws1 = K.conv3x3_mx8_num_partials(B, H, W), 0
+            self.P, ws1 = K.conv3x3_mx8_num_partials(B, H, W, N, self.c0, self.c1), 0
         self.part = torch.empty(self.P * 2 * N, **f32)
         ws2 = 0
         if self.need_dgrad:
             segc = [self.c0, self.c1] if self.c1 else [self.c0]
             pg, ws2 = K.igemm_query(T, GEMM_S1, B, H, W, N, 0, cin, segc, ks=self.ks)
             if self.mx8:
-                pg, ws2 = K.conv3x3_mx8_num_partials(B, H, W), 0
+                pg, ws2 = K.conv3x3_mx8_num_partials(B, H, W, cin, N, 0), 0
             for s in self.srcs:
                 if s.fused_bwd:
                     s.bpart_rows = pg

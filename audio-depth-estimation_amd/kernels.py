@@ -237,8 +237,19 @@ def mx8_pack(master, X, Y, transpose, w8, wsc):
     _lib.call('adn_mx8_pack', ptr(master), X, Y, int(transpose), ptr(w8), ptr(wsc), _stream())
 
 
-def conv3x3_mx8_num_partials(B, H, W):
-    return B * H * W // 128
+def conv3x3_mx8_num_partials(B, H, W, N=128, C0=64, C1=0):
+    """Stats partial rows the kernel writes for this shape (queried from the library: 128 or 256 pixels per workgroup)."""
+    d = AdnMx8ConvDesc()
+    d.B, d.H, d.W, d.C0, d.C1, d.N = B, H, W, C0, C1, N
+    d.in0 = d.sc0 = d.w = d.wsc = 1
+    d.in1 = d.sc1 = 1 if C1 else None
+    d.epi = EPI_Z_STATS
+    d.seg[0].channels, d.seg[0].out0 = N, 1
+    lib = _lib.load()
+    n = lib.adn_conv3x3_mx8_num_partials(C.byref(d))
+    if n < 0:
+        raise RuntimeError('adn_conv3x3_mx8 query failed: ' + lib.adn_last_error().decode())
+    return n
 
 
 def conv3x3_mx8(B, H, W, in0, sc0, in1, sc1, w8, wsc, N, epi, segs):

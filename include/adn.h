@@ -176,7 +176,7 @@ typedef struct {
   int32_t reserved;
   AdnEpiSeg seg[2];    /* bf16 tensors                                                             */
 } AdnMx8ConvDesc;
-int64_t adn_conv3x3_mx8_num_partials(const AdnMx8ConvDesc* d);   /* stats partial rows = B*H*W / 128 */
+int64_t adn_conv3x3_mx8_num_partials(const AdnMx8ConvDesc* d);   /* stats partial rows = B*H*W / rows per workgroup (128 | 256) */
 int adn_conv3x3_mx8(const AdnMx8ConvDesc* d, void* stream);
 
 /* ---- DoubleConv U-Net family (DoubleConv / Down / Up: binaural_attention_model.py:22-78, identical copies

@@ -71,7 +71,8 @@ def _quant_dev(x_bf16):
     return q8, sc
 
 
-CASES = [(2, 16, 32, 64, 0, 64), (1, 8, 16, 128, 64, 128), (2, 24, 48, 64, 64, 192), (3, 8, 32, 256, 0, 128)]
+CASES = [(2, 16, 32, 64, 0, 64), (1, 8, 16, 128, 64, 128), (2, 24, 48, 64, 64, 192), (3, 8, 32, 256, 0, 128),
+         (2, 256, 256, 64, 64, 64)]       # the last: 512 tiles of 16 x 16 pixels -> the tall 4 x 1-wave form (N = 64)
 
 
 @pytest.mark.parametrize('B,H,W,C0,C1,N', CASES)
@@ -97,7 +98,7 @@ def test_conv_forward_against_oracle(B, H, W, C0, C1, N):
     s8, ssc = K.mx8_pack_shapes(N, Cin, False)
     w8, wsc = torch.empty(s8, dtype=torch.uint8, device=DEV), torch.empty(ssc, dtype=torch.uint8, device=DEV)
     K.mx8_pack(torch.from_numpy(np.ascontiguousarray(w.transpose(0, 2, 3, 1))).to(DEV), N, Cin, False, w8, wsc)
-    P = K.conv3x3_mx8_num_partials(B, H, W)
+    P = K.conv3x3_mx8_num_partials(B, H, W, N, C0, C1)
     z = torch.full((B, H, W, N), float('nan'), dtype=torch.bfloat16, device=DEV)
     part = torch.full((P, 2, N), float('nan'), device=DEV)
     K.conv3x3_mx8(B, H, W, q0, s0, q1, s1, w8, wsc, N, K.EPI_Z_STATS,
@@ -147,7 +148,7 @@ def test_conv_dgrad_epilogues_against_oracle():
     a = _bf16(np.maximum(rng.standard_normal((B, H, W, Cin)), 0))
     zf = _bf16(rng.standard_normal((B, H, W, Cin)))
     mean, istd = rng.standard_normal(Cin).astype(np.float32), (1 + rng.random(Cin)).astype(np.float32)
-    P = K.conv3x3_mx8_num_partials(B, H, W)
+    P = K.conv3x3_mx8_num_partials(B, H, W, Cin, N, 0)
     segs, outs, parts = [], [], []
     for lo, hi in ((0, C0), (C0, Cin)):
         o = torch.full((B, H, W, hi - lo), float('nan'), dtype=torch.bfloat16, device=DEV)
@@ -180,7 +181,7 @@ def test_full_size_repeatability_and_error_behaviour():
     s8, ssc = K.mx8_pack_shapes(N, Cc, False)
     w8, wsc = torch.empty(s8, dtype=torch.uint8, device=DEV), torch.empty(ssc, dtype=torch.uint8, device=DEV)
     K.mx8_pack(master, N, Cc, False, w8, wsc)
-    P = K.conv3x3_mx8_num_partials(B, H, W)
+    P = K.conv3x3_mx8_num_partials(B, H, W, N, Cc, 0)
     outs = []
     for _ in range(3):
         z = torch.full((B, H, W, N), float('nan'), dtype=torch.bfloat16, device=DEV)

@@ -155,7 +155,7 @@ def mx8_main(args):
         out = torch.empty(Bm, H, H, N, device=DEV, dtype=T)
         P, wsb = K.igemm_query(T, K.GEMM_S1, Bm, H, H, C0, C1, N, [N], ks=3)
         ws = torch.empty(max(wsb, 16) // 4, device=DEV)
-        part = torch.empty(max(P, K.conv3x3_mx8_num_partials(Bm, H, H)) * 2 * N, device=DEV)
+        part = torch.empty(max(P, K.conv3x3_mx8_num_partials(Bm, H, H, N, C0, C1)) * 2 * N, device=DEV)
         w16 = torch.empty(N, K.s1_row_stride(T, 9, Cin), device=DEV, dtype=T)
         K.pack_rows(master, N, 9, Cin, w16)
         f16 = lambda: K.igemm(T, K.GEMM_S1, Bm, H, H, in0, in1, w16, N, 1, [K.Seg(N, out0=out, partials=part)], ws, ks=3)
