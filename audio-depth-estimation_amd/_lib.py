@@ -96,6 +96,9 @@ _PROTOS = {
     'adn_pack_weights': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     'adn_mx8_quantize': (C.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     'adn_mx8_pack': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    'adn_maxpool2_fwd_mx8': (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    'adn_upsample2x_fwd_mx8': (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p,
+                                         c_void_p, c_void_p]),
     'adn_bn_act_mx8': (C.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'adn_bn_bwd_apply_mx8': (C.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p]),

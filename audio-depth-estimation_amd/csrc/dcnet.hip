@@ -4,6 +4,7 @@
 // All activations NHWC in dtype T (f32 / bf16); 8 channels (16/32 bytes) per thread when C % 8 == 0,
 // scalar otherwise.  HBM roofline kernels: every tensor is read/written exactly once per pass.
 #include "adn_common.h"
+#include "mx8_quant.h"
 #include "epilogue.h"
 
 namespace {
@@ -30,7 +31,8 @@ __device__ __forceinline__ void storev(T* p, int64_t idx, const float* f) {
 // ---------------------------------------------------------------------------------------------------
 // MaxPool2d(2) (binaural_attention_model.py:47-50).  src [B][H][W][C] -> dst [B][H/2][W/2][C] (floor).
 template <typename T, int V>
-__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* src, T* dst, int B, int H, int W, int C) {
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* src, T* dst, int B, int H, int W, int C,
+                                                           uint2* q8 = nullptr, uint8_t* qsc = nullptr) {
   const int Ho = H >> 1, Wo = W >> 1, ncg = C / V;
   const int64_t work = (int64_t)B * Ho * Wo * ncg;
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < work; idx += (int64_t)gridDim.x * 256) {
@@ -49,6 +51,13 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* src, T* dst,
 #pragma unroll
     for (int k = 0; k < V; ++k) m[k] = fmaxf(fmaxf(v0[k], v1[k]), fmaxf(v2[k], v3[k]));
     storev<T, V>(dst, (((int64_t)b * Ho + oy) * Wo + ox) * C + cg * V, m);
+    if constexpr (V == 8 && sizeof(T) == 2) {
+      if (q8) {                  // MX-fp8 copy of the bf16 output for the fp8 conv path (the max of bf16 values is exact)
+        int byte;
+        q8[idx] = mx_quant8(m, byte);
+        if ((threadIdx.x & 3) == 0) qsc[idx >> 2] = (uint8_t)byte;
+      }
+    }
   }
 }
 
@@ -143,7 +152,8 @@ __device__ __forceinline__ void up_src(int o, int in, float r, int& i0, int& ip,
 
 template <typename T, int V>
 __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* src, T* dst, int B, int Hi, int Wi, int Ho,
-                                                             int Wo, int padT, int padL, int C) {
+                                                             int Wo, int padT, int padL, int C, uint2* q8 = nullptr,
+                                                             uint8_t* qsc = nullptr) {
   const int ncg = C / V;
   const int Hu = 2 * Hi, Wu = 2 * Wi;
   const float rh = Hu > 1 ? (float)(Hi - 1) / (float)(Hu - 1) : 0.f;
@@ -177,6 +187,15 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* src, T* ds
       for (int k = 0; k < V; ++k) o[k] = 0.f;
     }
     storev<T, V>(dst, idx * V, o);
+    if constexpr (V == 8 && sizeof(T) == 2) {
+      if (q8) {                  // MX-fp8 copy of exactly what the bf16 tensor holds
+#pragma unroll
+        for (int k = 0; k < V; ++k) o[k] = bf16_bits_to_f32(f32_to_bf16_bits(o[k]));
+        int byte;
+        q8[idx] = mx_quant8(o, byte);
+        if ((threadIdx.x & 3) == 0) qsc[idx >> 2] = (uint8_t)byte;
+      }
+    }
   }
 }
 
@@ -553,6 +572,34 @@ extern "C" int adn_maxpool2_fwd(const void* src, void* dst, int32_t B, int32_t H
     auto d = reinterpret_cast<float*>(dst);
     ADN_DISPATCH_V(maxpool2_fwd_kernel, float, dim3(blocks_for(work)), st, s, d, B, H, W, C);
   }
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}
+
+// bf16 forward kernels that also write the MX-fp8 copy of their output (C % 32 == 0), for the fp8 conv path
+extern "C" int adn_maxpool2_fwd_mx8(const void* src, void* dst, int32_t B, int32_t H, int32_t W, int32_t C, void* out8,
+                                    void* out_scales, void* stream) {
+  ADN_CHECK_ARG(src && dst && out8 && out_scales && B > 0 && H > 1 && W > 1 && C > 0 && C % 32 == 0,
+                "adn_maxpool2_fwd_mx8: bad arguments (C=%d must be a multiple of 32)", C);
+  const int64_t work = (int64_t)B * (H / 2) * (W / 2) * (C / 8);
+  hipLaunchKernelGGL((maxpool2_fwd_kernel<uint16_t, 8>), dim3(blocks_for(work)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const uint16_t*>(src), reinterpret_cast<uint16_t*>(dst), B, H, W, C,
+                     reinterpret_cast<uint2*>(out8), reinterpret_cast<uint8_t*>(out_scales));
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}
+
+extern "C" int adn_upsample2x_fwd_mx8(const void* src, void* dst, int32_t B, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo,
+                                      int32_t C, void* out8, void* out_scales, void* stream) {
+  ADN_CHECK_ARG(src && dst && out8 && out_scales && B > 0 && Hi > 0 && Wi > 0 && C > 0 && C % 32 == 0,
+                "adn_upsample2x_fwd_mx8: bad arguments (C=%d must be a multiple of 32)", C);
+  ADN_CHECK_ARG(Ho >= 2 * Hi && Wo >= 2 * Wi, "adn_upsample2x_fwd_mx8: target %dx%d smaller than 2x source %dx%d", Ho, Wo, Hi, Wi);
+  const int padT = (Ho - 2 * Hi) / 2, padL = (Wo - 2 * Wi) / 2;
+  const int64_t work = (int64_t)B * Ho * Wo * (C / 8);
+  hipLaunchKernelGGL((upsample2x_fwd_kernel<uint16_t, 8>), dim3(blocks_for(work)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const uint16_t*>(src),
+                     reinterpret_cast<uint16_t*>(dst), B, Hi, Wi, Ho, Wo, padT, padL, C, reinterpret_cast<uint2*>(out8),
+                     reinterpret_cast<uint8_t*>(out_scales));
   ADN_CHECK_LAUNCH();
   return ADN_OK;
 }

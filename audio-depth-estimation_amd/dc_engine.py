@@ -321,7 +321,12 @@ class MaxPool2(Op):
         src.consumers.append(self)
 
     def fwd(self, eng, training):
-        K.maxpool2_fwd(self.src.data, self.out.data)
+        o = self.out
+        if o.want_q8 and o.q8 is not None and o.data.dtype == torch.bfloat16 and o.C % 32 == 0:
+            K.maxpool2_fwd_mx8(self.src.data, o.data, o.q8, o.q8s)       # the fp8 conv's operand copy comes with the output
+            o.q8_serial = eng.fwd_serial
+        else:
+            K.maxpool2_fwd(self.src.data, o.data)
 
     def bwd(self, eng):
         K.maxpool2_bwd(self.out.grad, self.src.data, self.src.grad, accumulate=self.src.written)
@@ -337,7 +342,12 @@ class Upsample2x(Op):
         src.consumers.append(self)
 
     def fwd(self, eng, training):
-        K.upsample2x_fwd(self.src.data, self.out.data)
+        o = self.out
+        if o.want_q8 and o.q8 is not None and o.data.dtype == torch.bfloat16 and o.C % 32 == 0:
+            K.upsample2x_fwd_mx8(self.src.data, o.data, o.q8, o.q8s)
+            o.q8_serial = eng.fwd_serial
+        else:
+            K.upsample2x_fwd(self.src.data, o.data)
 
     def bwd(self, eng):
         K.upsample2x_bwd(self.out.grad, self.src.grad, accumulate=self.src.written)

@@ -488,6 +488,21 @@ def maxpool2_fwd(src, dst):
     _lib.call('adn_maxpool2_fwd', ptr(src), ptr(dst), B, H, W, Cc, dtype_code(src.dtype), _stream())
 
 
+def maxpool2_fwd_mx8(src, dst, out8, out_scales):
+    """maxpool2_fwd (bf16) that also writes the MX-fp8 copy of dst."""
+    B, H, W, Cc = src.shape
+    _dev(src, dst, out8, out_scales)
+    _lib.call('adn_maxpool2_fwd_mx8', ptr(src), ptr(dst), B, H, W, Cc, ptr(out8), ptr(out_scales), _stream())
+
+
+def upsample2x_fwd_mx8(src, dst, out8, out_scales):
+    """upsample2x_fwd (bf16) that also writes the MX-fp8 copy of dst."""
+    B, Hi, Wi, Cc = src.shape
+    _dev(src, dst, out8, out_scales)
+    _lib.call('adn_upsample2x_fwd_mx8', ptr(src), ptr(dst), B, Hi, Wi, dst.shape[1], dst.shape[2], Cc, ptr(out8),
+              ptr(out_scales), _stream())
+
+
 def maxpool2_bwd(gdst, y, gsrc, accumulate):
     B, H, W, Cc = y.shape
     _dev(gdst, y, gsrc)

@@ -163,6 +163,10 @@ int adn_bn_act_mx8(const void* z, int64_t pixels, int32_t C, const float* scale,
                    void* out8, void* out_scales, void* stream);
 int adn_bn_bwd_apply_mx8(void* g, const void* z, int64_t pixels, int32_t C, const float* scale, const float* mean,
                          const float* istd, const float* coef, void* out8, void* out_scales, void* stream);
+int adn_maxpool2_fwd_mx8(const void* src, void* dst, int32_t B, int32_t H, int32_t W, int32_t C, void* out8,
+                         void* out_scales, void* stream);      /* adn_maxpool2_fwd (bf16) + fp8 copy of dst */
+int adn_upsample2x_fwd_mx8(const void* src, void* dst, int32_t B, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo,
+                           int32_t C, void* out8, void* out_scales, void* stream);   /* adn_upsample2x_fwd (bf16) + copy */
 typedef struct {
   int32_t B, H, W;     /* common grid of input and output (H % 8 == 0, W % 16 == 0)                 */
   int32_t C0, C1, N;   /* gathered sources (virtual concat, multiples of 64; C1 may be 0), outputs  */

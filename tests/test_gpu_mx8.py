@@ -196,3 +196,51 @@ def test_full_size_repeatability_and_error_behaviour():
                       K.EPI_Z_STATS, [K.Seg(N, out0=outs[0][0], partials=outs[0][1])])
     with pytest.raises(RuntimeError):
         K.mx8_quantize(x.cpu(), q, s)
+
+
+def test_fused_fp8_copies_equal_quantizing_the_bf16_output():
+    """bn_act_mx8 / bn_bwd_apply_mx8 / maxpool2_fwd_mx8 / upsample2x_fwd_mx8: the bf16 result is the plain kernel's (bit for
+    bit) and the fp8 copy written alongside is bit-identical to adn_mx8_quantize of that result."""
+    from audio_depth_estimation_amd import kernels as K
+    g = torch.Generator(device=DEV).manual_seed(9)
+    B, H, W, Cc = 2, 16, 24, 96
+    u8 = lambda *shape: torch.full(shape, 0xAA, dtype=torch.uint8, device=DEV)
+
+    def check(out_bf16, q8, qs):
+        want8, wants = _quant_dev(out_bf16)
+        assert torch.equal(qs, wants)
+        nz = (want8 & 0x7f) != 0
+        assert torch.equal(q8[nz], want8[nz]) and not bool(((q8 & 0x7f)[~nz]).any())
+
+    z = (torch.randn(B, H, W, Cc, device=DEV, generator=g) * 3).to(torch.bfloat16)
+    scale, shift = torch.rand(Cc, device=DEV, generator=g) + 0.5, torch.randn(Cc, device=DEV, generator=g)
+    y0, y1 = torch.empty_like(z), torch.empty_like(z)
+    q8, qs = u8(B, H, W, Cc), u8(B, H, W, Cc // 32)
+    K.bn_act(z, B * H * W, Cc, scale, shift, 0.0, None, y0)
+    K.bn_act_mx8(z, B * H * W, Cc, scale, shift, y1, q8, qs)
+    assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
+    check(y1, q8, qs)
+
+    gr = (torch.randn(B, H, W, Cc, device=DEV, generator=g) * 1e-3).to(torch.bfloat16)
+    mean, istd = torch.randn(Cc, device=DEV, generator=g), torch.rand(Cc, device=DEV, generator=g) + 0.5
+    coef = torch.randn(2 * Cc, device=DEV, generator=g) * 1e-4
+    g0, g1 = gr.clone(), gr.clone()
+    K.bn_bwd_apply(g0, z, B * H * W, Cc, scale, mean, istd, coef)
+    K.bn_bwd_apply_mx8(g1, z, B * H * W, Cc, scale, mean, istd, coef, q8, qs)
+    assert torch.equal(g0.view(torch.int16), g1.view(torch.int16))
+    check(g1, q8, qs)
+
+    p0, p1 = torch.empty(B, H // 2, W // 2, Cc, dtype=torch.bfloat16, device=DEV), torch.empty(B, H // 2, W // 2, Cc, dtype=torch.bfloat16, device=DEV)
+    q8p, qsp = u8(B, H // 2, W // 2, Cc), u8(B, H // 2, W // 2, Cc // 32)
+    K.maxpool2_fwd(z, p0)
+    K.maxpool2_fwd_mx8(z, p1, q8p, qsp)
+    assert torch.equal(p0.view(torch.int16), p1.view(torch.int16))
+    check(p1, q8p, qsp)
+
+    Ho, Wo = 2 * H + 1, 2 * W + 2                        # padded target as in Up.forward (F.pad to the skip's size)
+    u0, u1 = torch.empty(B, Ho, Wo, Cc, dtype=torch.bfloat16, device=DEV), torch.empty(B, Ho, Wo, Cc, dtype=torch.bfloat16, device=DEV)
+    q8u, qsu = u8(B, Ho, Wo, Cc), u8(B, Ho, Wo, Cc // 32)
+    K.upsample2x_fwd(z, u0)
+    K.upsample2x_fwd_mx8(z, u1, q8u, qsu)
+    assert torch.equal(u0.view(torch.int16), u1.view(torch.int16))
+    check(u1, q8u, qsu)
