@@ -14,7 +14,7 @@ from __future__ import annotations
 import torch
 
 from . import kernels as K
-from .dc_engine import Act, ConvBNReLU, DCEngine, Head1x1, Op, flag_solo
+from .dc_engine import Act, ConvBNReLU, DCEngine, Head1x1, Op, flag_solo, mark_tail_writers
 from .engine import GraphedStep
 from ._lib import EPI_ACT, EPI_ADD, GEMM_S1
 
@@ -233,6 +233,7 @@ class AdaBinsEngine(DCEngine):
             for a in br.acts:
                 flag_solo(a)
                 a.alloc(B, self.dtype, dev)
+            mark_tail_writers(allops + [br.head])
             for op in allops + [br.head]:
                 op.prepare(self)
                 ws = max(ws, op.workspace_bytes(self))

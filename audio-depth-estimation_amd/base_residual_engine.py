@@ -11,7 +11,7 @@ from __future__ import annotations
 import torch
 
 from . import kernels as K
-from .dc_engine import DCEngine, Head1x1, flag_solo
+from .dc_engine import DCEngine, Head1x1, flag_solo, mark_tail_writers
 from .engine import GraphedStep
 
 
@@ -65,6 +65,7 @@ class BaseResidualEngine(DCEngine):
         for a in self.acts:
             flag_solo(a)
             a.alloc(B, self.dtype, x.device)
+        mark_tail_writers(ops + [self.head_base, self.head_res])
         ws = 1 << 16
         for op in ops + [self.head_base, self.head_res]:
             op.prepare(self)

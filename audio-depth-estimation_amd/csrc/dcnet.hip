@@ -86,13 +86,77 @@ __global__ __launch_bounds__(256) void pixel_shuffle2_kernel(const T* src, T* ds
   }
 }
 
+// ---- fused tail of a gradient's LAST writer (round 2): when the kernel that completes d loss / d y of a ConvBNReLU output is
+// a max-pool or upsample backward, it also applies the ReLU mask (y > 0) and accumulates the BatchNorm-backward sums
+// (sum g, sum g * xhat) -- the separate relu_bwd_stats pass (read g, y, z; write g) shrinks to one extra read of z (and y).
+// Thread t keeps channel group t % ncg for its whole grid-stride loop (the stride is a multiple of 256 and ncg | 256);
+// partials [gridDim.x][2][C] for adn_bn_bwd_finalize.
+struct TailStats {
+  const void* y;        // activated forward tensor of the SOURCE record (mask); max-pool already holds it
+  const void* z;        // raw conv output of the source record, nullptr = tail not fused
+  const float* mean;
+  const float* istd;
+  float* partials;
+};
+
+template <typename T, int V>
+__device__ __forceinline__ void tail_apply(const TailStats& ts, int64_t e, const float* mu, const float* is, const float* yv,
+                                           float* g, float* s1, float* s2) {
+  float zv[V];
+  loadv<T, V>(reinterpret_cast<const T*>(ts.z), e, zv);
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+    g[k] = yv[k] > 0.f ? g[k] : 0.f;
+    s1[k] += g[k];
+    s2[k] += g[k] * ((zv[k] - mu[k]) * is[k]);
+  }
+}
+// per-thread channel constants: the thread's channel group is fixed over its grid-stride loop
+template <int V>
+__device__ __forceinline__ void tail_consts(const TailStats& ts, int ncg, float* mu, float* is) {
+#pragma unroll
+  for (int k = 0; k < V; ++k) mu[k] = is[k] = 0.f;
+  if (ts.z) {
+    const int c0 = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) % ncg) * V;
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      mu[k] = ts.mean[c0 + k];
+      is[k] = ts.istd[c0 + k];
+    }
+  }
+}
+
+// block reduction of the per-thread sums (V == 8): threads t, t + ncg, t + 2 ncg, ... share a channel group
+__device__ __forceinline__ void tail_reduce8(const TailStats& ts, int C, int ncg, const float* s1, const float* s2) {
+  __shared__ float tail_red[256 * 16];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    tail_red[threadIdx.x * 16 + k] = s1[k];
+    tail_red[threadIdx.x * 16 + 8 + k] = s2[k];
+  }
+  __syncthreads();
+  float* po = ts.partials + (int64_t)blockIdx.x * 2 * C;
+  const int per = 256 / ncg;
+  for (int t = threadIdx.x; t < ncg * 16; t += 256) {
+    const int gl = t >> 4, k = t & 15;
+    float sum = 0.f;
+    for (int r = 0; r < per; ++r) sum += tail_red[(r * ncg + gl) * 16 + k];
+    po[(k >> 3) * C + gl * 8 + (k & 7)] = sum;
+  }
+}
+
 // Backward: the gradient of a window goes to its FIRST maximum in scan order (strict >), as torch does.
 // gsrc (+)= routed gdst; pixels of a trailing odd row/column get 0.
 template <typename T, int V>
 __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* gdst, const T* y, T* gsrc, int B, int H, int W,
-                                                           int C, int accumulate) {
+                                                           int C, int accumulate, TailStats ts = TailStats{}) {
   const int Ho = H >> 1, Wo = W >> 1, Hc = (H + 1) >> 1, Wc = (W + 1) >> 1, ncg = C / V;
   const int64_t work = (int64_t)B * Hc * Wc * ncg;
+  float ts1[V], ts2[V], tmu[V], tis[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) ts1[k] = ts2[k] = 0.f;
+  tail_consts<V>(ts, ncg, tmu, tis);
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < work; idx += (int64_t)gridDim.x * 256) {
     const int cg = (int)(idx % ncg);
     int64_t pix = idx / ncg;
@@ -125,8 +189,25 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* gdst, const 
         if (accumulate) loadv<T, V>(gsrc, base + off[q], o);
 #pragma unroll
         for (int k = 0; k < V; ++k) o[k] = (accumulate ? o[k] : 0.f) + (arg[k] == q ? gd[k] : 0.f);
+        if (ts.z) tail_apply<T, V>(ts, base + off[q], tmu, tis, v[q], o, ts1, ts2);
         storev<T, V>(gsrc, base + off[q], o);
       }
+    } else if (ts.z) {
+      // trailing odd row / column: no pooled gradient; the pixel keeps its accumulated gradient (or 0), masked
+      for (int dy = 0; dy < 2; ++dy)
+        for (int dx = 0; dx < 2; ++dx)
+          if (2 * wy + dy < H && 2 * wx + dx < W) {
+            const int64_t e = base + ((int64_t)dy * W + dx) * C;
+            float o[V], yv[V];
+            if (accumulate) loadv<T, V>(gsrc, e, o);
+            else {
+#pragma unroll
+              for (int k = 0; k < V; ++k) o[k] = 0.f;
+            }
+            loadv<T, V>(y, e, yv);
+            tail_apply<T, V>(ts, e, tmu, tis, yv, o, ts1, ts2);
+            storev<T, V>(gsrc, e, o);
+          }
     } else if (!accumulate) {
       float zero[V];
 #pragma unroll
@@ -135,6 +216,9 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* gdst, const 
         for (int dx = 0; dx < 2; ++dx)
           if (2 * wy + dy < H && 2 * wx + dx < W) storev<T, V>(gsrc, base + ((int64_t)dy * W + dx) * C, zero);
     }
+  }
+  if constexpr (V == 8) {
+    if (ts.z) tail_reduce8(ts, C, ncg, ts1, ts2);
   }
 }
 
@@ -229,8 +313,13 @@ __device__ __forceinline__ int up_candidates(int i, int in, int out, float r, in
 
 template <typename T, int V>
 __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* gdst, T* gsrc, int B, int Hi, int Wi, int Ho,
-                                                             int Wo, int padT, int padL, int C, int accumulate) {
+                                                             int Wo, int padT, int padL, int C, int accumulate,
+                                                             TailStats ts = TailStats{}) {
   const int ncg = C / V;
+  float ts1[V], ts2[V], tmu[V], tis[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) ts1[k] = ts2[k] = 0.f;
+  tail_consts<V>(ts, ncg, tmu, tis);
   const int Hu = 2 * Hi, Wu = 2 * Wi;
   const float rh = Hu > 1 ? (float)(Hi - 1) / (float)(Hu - 1) : 0.f;
   const float rw = Wu > 1 ? (float)(Wi - 1) / (float)(Wu - 1) : 0.f;
@@ -265,7 +354,15 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* gdst, T* g
         for (int k = 0; k < V; ++k) acc[k] += w * g[k];
       }
     }
+    if (ts.z) {
+      float yv[V];
+      loadv<T, V>(reinterpret_cast<const T*>(ts.y), idx * V, yv);
+      tail_apply<T, V>(ts, idx * V, tmu, tis, yv, acc, ts1, ts2);
+    }
     storev<T, V>(gsrc, idx * V, acc);
+  }
+  if constexpr (V == 8) {
+    if (ts.z) tail_reduce8(ts, C, ncg, ts1, ts2);
   }
 }
 
@@ -600,6 +697,61 @@ extern "C" int adn_upsample2x_fwd_mx8(const void* src, void* dst, int32_t B, int
                      reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const uint16_t*>(src),
                      reinterpret_cast<uint16_t*>(dst), B, Hi, Wi, Ho, Wo, padT, padL, C, reinterpret_cast<uint2*>(out8),
                      reinterpret_cast<uint8_t*>(out_scales));
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}
+
+// Grid of the tail-fused backward kernels for `work` thread items (= partial rows they write); 0 when the channel count does not
+// allow the fusion (needs C % 8 == 0 and C / 8 a divisor of 256).
+extern "C" int64_t adn_tail_stats_blocks(int64_t work, int32_t C) {
+  if (C <= 0 || (C & 7) != 0 || 256 % (C / 8) != 0 || work <= 0) return 0;
+  int64_t b = adn_cdiv(work, 256);
+  if (b > 2048) b = 2048;
+  return b;
+}
+
+extern "C" int adn_maxpool2_bwd_tail(const void* gdst, const void* y, void* gsrc, int32_t B, int32_t H, int32_t W, int32_t C,
+                                     int32_t accumulate, int32_t dtype, const void* z, const float* mean, const float* istd,
+                                     float* partials, void* stream) {
+  ADN_CHECK_ARG(gdst && y && gsrc && z && mean && istd && partials && B > 0 && H > 1 && W > 1, "adn_maxpool2_bwd_tail: bad arguments");
+  ADN_CHECK_ARG(dtype == ADN_F32 || dtype == ADN_BF16, "adn_maxpool2_bwd_tail: bad dtype %d", dtype);
+  const int64_t work = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);
+  const int64_t blocks = adn_tail_stats_blocks(work, C);
+  ADN_CHECK_ARG(blocks > 0, "adn_maxpool2_bwd_tail: C=%d not supported", C);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  TailStats ts{y, z, mean, istd, partials};
+  if (dtype == ADN_BF16)
+    hipLaunchKernelGGL((maxpool2_bwd_kernel<uint16_t, 8>), dim3((unsigned)blocks), dim3(256), 0, st,
+                       reinterpret_cast<const uint16_t*>(gdst), reinterpret_cast<const uint16_t*>(y),
+                       reinterpret_cast<uint16_t*>(gsrc), B, H, W, C, accumulate, ts);
+  else
+    hipLaunchKernelGGL((maxpool2_bwd_kernel<float, 8>), dim3((unsigned)blocks), dim3(256), 0, st,
+                       reinterpret_cast<const float*>(gdst), reinterpret_cast<const float*>(y), reinterpret_cast<float*>(gsrc), B,
+                       H, W, C, accumulate, ts);
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}
+
+extern "C" int adn_upsample2x_bwd_tail(const void* gdst, void* gsrc, int32_t B, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo,
+                                       int32_t C, int32_t accumulate, int32_t dtype, const void* y, const void* z,
+                                       const float* mean, const float* istd, float* partials, void* stream) {
+  ADN_CHECK_ARG(gdst && gsrc && y && z && mean && istd && partials && B > 0 && Hi > 0 && Wi > 0, "adn_upsample2x_bwd_tail: bad arguments");
+  ADN_CHECK_ARG(Ho >= 2 * Hi && Wo >= 2 * Wi, "adn_upsample2x_bwd_tail: target %dx%d smaller than 2x source %dx%d", Ho, Wo, Hi, Wi);
+  ADN_CHECK_ARG(dtype == ADN_F32 || dtype == ADN_BF16, "adn_upsample2x_bwd_tail: bad dtype %d", dtype);
+  const int padT = (Ho - 2 * Hi) / 2, padL = (Wo - 2 * Wi) / 2;
+  const int64_t work = (int64_t)B * Hi * Wi * (C / 8);
+  const int64_t blocks = adn_tail_stats_blocks(work, C);
+  ADN_CHECK_ARG(blocks > 0, "adn_upsample2x_bwd_tail: C=%d not supported", C);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  TailStats ts{y, z, mean, istd, partials};
+  if (dtype == ADN_BF16)
+    hipLaunchKernelGGL((upsample2x_bwd_kernel<uint16_t, 8>), dim3((unsigned)blocks), dim3(256), 0, st,
+                       reinterpret_cast<const uint16_t*>(gdst), reinterpret_cast<uint16_t*>(gsrc), B, Hi, Wi, Ho, Wo, padT, padL, C,
+                       accumulate, ts);
+  else
+    hipLaunchKernelGGL((upsample2x_bwd_kernel<float, 8>), dim3((unsigned)blocks), dim3(256), 0, st,
+                       reinterpret_cast<const float*>(gdst), reinterpret_cast<float*>(gsrc), B, Hi, Wi, Ho, Wo, padT, padL, C,
+                       accumulate, ts);
   ADN_CHECK_LAUNCH();
   return ADN_OK;
 }

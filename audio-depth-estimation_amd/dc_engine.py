@@ -19,6 +19,8 @@ towards its start because backward visits the ops in reverse parameters() order.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
@@ -49,6 +51,8 @@ class Act:
         self.q8 = self.q8s = None    # MX-fp8 copy of .data (e4m3 bytes + E8M0 scales) for the fp8 conv path
         self.q8_serial = -1          # forward pass the copy belongs to
         self.want_q8 = False         # some consumer is an MX-fp8 conv: the producer writes the copy with its output
+        self.tail_writer = None      # the op that writes this record's gradient LAST in the backward pass, when it is a max-pool /
+        self.tail_fused = False      # upsample: that kernel then applies the ReLU mask + BN-backward sums (no relu_bwd_stats pass)
 
     def target(self):
         return self.alias_of if self.alias_of is not None else self
@@ -267,7 +271,7 @@ class ConvBNReLU(Op):
         N, bn = self.N, self.bn
         pixels = B * o.H * o.W
         G = o.grad
-        if not o.fused_bwd:
+        if not o.fused_bwd and not o.tail_fused:
             K.relu_bwd_stats(G, o.data, o.z, o.mean, o.istd, pixels, N, o.bpart)
         fg = lambda p: eng._flat_slice(eng.flat_g, p)
         if self.padded:
@@ -328,9 +332,17 @@ class MaxPool2(Op):
         else:
             K.maxpool2_fwd(self.src.data, o.data)
 
+    def prepare(self, eng):
+        s_ = self.src
+        _tail_setup(self, eng, eng.B * ((s_.H + 1) // 2) * ((s_.W + 1) // 2) * (s_.C // 8))
+
     def bwd(self, eng):
-        K.maxpool2_bwd(self.out.grad, self.src.data, self.src.grad, accumulate=self.src.written)
-        self.src.written = True
+        s_ = self.src
+        if self.tail:
+            K.maxpool2_bwd_tail(self.out.grad, s_.data, s_.grad, s_.written, s_.z, s_.mean, s_.istd, s_.bpart)
+        else:
+            K.maxpool2_bwd(self.out.grad, s_.data, s_.grad, accumulate=s_.written)
+        s_.written = True
 
 
 class Upsample2x(Op):
@@ -349,9 +361,17 @@ class Upsample2x(Op):
         else:
             K.upsample2x_fwd(self.src.data, o.data)
 
+    def prepare(self, eng):
+        s_ = self.src
+        _tail_setup(self, eng, eng.B * s_.H * s_.W * (s_.C // 8))
+
     def bwd(self, eng):
-        K.upsample2x_bwd(self.out.grad, self.src.grad, accumulate=self.src.written)
-        self.src.written = True
+        s_ = self.src
+        if self.tail:
+            K.upsample2x_bwd_tail(self.out.grad, s_.grad, s_.written, s_.data, s_.z, s_.mean, s_.istd, s_.bpart)
+        else:
+            K.upsample2x_bwd(self.out.grad, s_.grad, accumulate=s_.written)
+        s_.written = True
 
 
 class ConvT2x2(Op):
@@ -644,6 +664,40 @@ def flag_solo(a):
         a.C = (a.C + 63) // 64 * 64
 
 
+def mark_tail_writers(ops):
+    """``ops``: the tape in forward order (heads last).  The backward pass walks it in reverse, so the consumer that sits
+    FIRST in the tape writes a record's gradient last; remember it when it is a max-pool or upsample op."""
+    pos = {id(op): i for i, op in enumerate(ops)}
+    seen = {}
+    for op in ops:
+        for a in list(getattr(op, 'srcs', [])) + [getattr(op, 'src', None)]:
+            if a is not None:
+                seen[id(a)] = a
+    for a in seen.values():
+        a.tail_writer = None
+        cons = [c for c in a.consumers]
+        if not cons or not isinstance(a.producer, ConvBNReLU):
+            continue
+        first = min(cons, key=lambda c: pos.get(id(c), 1 << 30))
+        if isinstance(first, (MaxPool2, Upsample2x)) and id(first) in pos:
+            a.tail_writer = first
+
+
+def _tail_setup(op, eng, work):
+    """Shared by MaxPool2 / Upsample2x.prepare: fuse the source record's ReLU mask + BN-backward statistics into this op's
+    backward kernel when this op is the record's last gradient writer."""
+    s_ = op.src
+    op.tail = False
+    if (s_.tail_writer is op and isinstance(s_.producer, ConvBNReLU) and not s_.fused_bwd and s_.needs_grad and
+            s_.alias_of is None and s_.pair_data is None and not hasattr(s_, 'C_real') and s_.z is not None and
+            os.environ.get('ADN_NO_TAIL_FUSION') is None):
+        P = K.tail_stats_blocks(work, s_.C)
+        if P > 0:
+            s_.tail_fused, s_.bpart_rows = True, P
+            s_.bpart = torch.empty(P * 2 * s_.C, dtype=torch.float32, device=eng.dev)
+            op.tail = True
+
+
 class DCEngine(FlatParamEngine):
     """Runs a DoubleConv-family module through libadn.  ``build(engine, B, C, H, W)`` (supplied by the model
     mirror) returns (inputs, ops, head): ``inputs`` = [(Act, first channel, channels)] slices of the NCHW network
@@ -705,6 +759,7 @@ class DCEngine(FlatParamEngine):
         for a in self.acts:
             flag_solo(a)
             a.alloc(B, self.dtype, x.device)
+        mark_tail_writers(self.ops + [self.head])
         ws = 16
         for op in self.ops + [self.head]:
             op.prepare(self)

@@ -510,6 +510,26 @@ def maxpool2_bwd(gdst, y, gsrc, accumulate):
               dtype_code(y.dtype), _stream())
 
 
+def tail_stats_blocks(work, Cc):
+    """Partial rows the tail-fused backward kernels write for ``work`` thread items (0: this channel count is not fusable)."""
+    return _lib.load().adn_tail_stats_blocks(work, Cc)
+
+
+def maxpool2_bwd_tail(gdst, y, gsrc, accumulate, z, mean, istd, partials):
+    """maxpool2_bwd that is the last writer of gsrc: + ReLU mask of y and BN-backward partial sums."""
+    B, H, W, Cc = y.shape
+    _dev(gdst, y, gsrc, z, mean, istd, partials)
+    _lib.call('adn_maxpool2_bwd_tail', ptr(gdst), ptr(y), ptr(gsrc), B, H, W, Cc, int(bool(accumulate)), dtype_code(y.dtype),
+              ptr(z), ptr(mean), ptr(istd), ptr(partials), _stream())
+
+
+def upsample2x_bwd_tail(gdst, gsrc, accumulate, y, z, mean, istd, partials):
+    B, Hi, Wi, Cc = gsrc.shape
+    _dev(gdst, gsrc, y, z, mean, istd, partials)
+    _lib.call('adn_upsample2x_bwd_tail', ptr(gdst), ptr(gsrc), B, Hi, Wi, gdst.shape[1], gdst.shape[2], Cc,
+              int(bool(accumulate)), dtype_code(gsrc.dtype), ptr(y), ptr(z), ptr(mean), ptr(istd), ptr(partials), _stream())
+
+
 def upsample2x_fwd(src, dst):
     """Bilinear x2 (align_corners=True) of src [B,Hi,Wi,C], zero padded into dst [B,Ho,Wo,C]."""
     B, Hi, Wi, Cc = src.shape

@@ -185,6 +185,17 @@ int adn_conv3x3_mx8(const AdnMx8ConvDesc* d, void* stream);
 
 /* ---- DoubleConv U-Net family (DoubleConv / Down / Up: binaural_attention_model.py:22-78, identical copies
  * rgb_depth_model.py:21-77, adabins_distillation_model.py:27-82).  NHWC activations in dtype. ---- */
+/* Tail-fused forms of adn_maxpool2_bwd / adn_upsample2x_bwd: when this kernel is the LAST writer of the gradient of a
+ * ConvBNReLU output it also applies that output's ReLU mask (y > 0) and writes the BatchNorm-backward partial sums
+ * [adn_tail_stats_blocks(work, C)][2][C] (what adn_relu_bwd_stats would do in a separate pass over the tensor).
+ * work = B * ceil(H/2) * ceil(W/2) * C/8 (max-pool) or B * Hi * Wi * C/8 (upsample). */
+int64_t adn_tail_stats_blocks(int64_t work, int32_t C);
+int adn_maxpool2_bwd_tail(const void* gdst, const void* y, void* gsrc, int32_t B, int32_t H, int32_t W, int32_t C,
+                          int32_t accumulate, int32_t dtype, const void* z, const float* mean, const float* istd,
+                          float* partials, void* stream);
+int adn_upsample2x_bwd_tail(const void* gdst, void* gsrc, int32_t B, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo,
+                            int32_t C, int32_t accumulate, int32_t dtype, const void* y, const void* z, const float* mean,
+                            const float* istd, float* partials, void* stream);
 /* nn.MaxPool2d(2): src [B][H][W][C] -> dst [B][H/2][W/2][C]; backward routes each window's gradient to its
  * first maximum (torch's tie rule), gsrc = (accumulate ? gsrc : 0) + routed. */
 int adn_maxpool2_fwd(const void* src, void* dst, int32_t B, int32_t H, int32_t W, int32_t C,

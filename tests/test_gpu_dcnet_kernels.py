@@ -493,3 +493,53 @@ def test_clamp_range_forward_backward():
     y = torch.clamp(xr, 0, 30.0)
     y.backward(go)
     assert torch.equal(out, y.detach()) and torch.equal(gx, xr.grad)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(2, 64, 16, 24), (3, 128, 9, 7), (1, 256, 4, 4)])
+def test_tail_fused_backward_kernels_match_the_two_pass_form(dtype, shape):
+    """adn_maxpool2_bwd_tail / adn_upsample2x_bwd_tail (the last gradient writer also applies the ReLU mask and the
+    BatchNorm-backward sums) against the plain backward kernel followed by adn_relu_bwd_stats: gradients bit-identical, the
+    per-channel sums equal up to the summation order."""
+    B, Cc, H, W = shape
+    k = K()
+    torch.manual_seed(5)
+    y = torch.relu(rounded(torch.randn(B, H, W, Cc), dtype)).to(dtype).to(DEV)          # forward output (post-ReLU)
+    z = rounded(torch.randn(B, H, W, Cc), dtype).to(dtype).to(DEV)
+    mean, istd = torch.randn(Cc, device=DEV), torch.rand(Cc, device=DEV) + 0.5
+    old = rounded(torch.randn(B, H, W, Cc) * 0.1, dtype).to(dtype).to(DEV)
+    sums = lambda part, rows: part.view(rows, 2, Cc).double().sum(0)
+    # (bf16: the fused kernels sum the f32 value BEFORE it is rounded for storage, like the dgrad epilogue does; the
+    #  two-pass form sums the stored bf16 values -- rounding noise of 2^-9 per element, averaged)
+    stol = 1e-4 if dtype == torch.float32 else 4e-3
+    # ---- max-pool (odd sizes: trailing row / column), accumulating and not
+    gd = rounded(torch.randn(B, H // 2, W // 2, Cc), dtype).to(dtype).to(DEV)
+    for acc in (True, False):
+        g0, g1 = old.clone(), old.clone()
+        k.maxpool2_bwd(gd, y, g0, acc)
+        P0 = k.relu_bwd_stats_num_partials(B * H * W, Cc)
+        p0 = torch.full((P0 * 2 * Cc,), float('nan'), device=DEV)
+        k.relu_bwd_stats(g0, y, z, mean, istd, B * H * W, Cc, p0)
+        P1 = k.tail_stats_blocks(B * ((H + 1) // 2) * ((W + 1) // 2) * (Cc // 8), Cc)
+        assert P1 > 0
+        p1 = torch.full((P1 * 2 * Cc,), float('nan'), device=DEV)
+        k.maxpool2_bwd_tail(gd, y, g1, acc, z, mean, istd, p1)
+        assert torch.equal(g0, g1)
+        ref = sums(p0, P0)
+        assert float((sums(p1, P1) - ref).abs().max()) <= stol * float(ref.abs().max()) + 1e-6
+    # ---- upsample (target padded by one row / two columns as in Up.forward)
+    Ho, Wo = 2 * H + 1, 2 * W + 2
+    gu = rounded(torch.randn(B, Ho, Wo, Cc), dtype).to(dtype).to(DEV)
+    for acc in (True, False):
+        g0, g1 = old.clone(), old.clone()
+        k.upsample2x_bwd(gu, g0, acc)
+        P0 = k.relu_bwd_stats_num_partials(B * H * W, Cc)
+        p0 = torch.full((P0 * 2 * Cc,), float('nan'), device=DEV)
+        k.relu_bwd_stats(g0, y, z, mean, istd, B * H * W, Cc, p0)
+        P1 = k.tail_stats_blocks(B * H * W * (Cc // 8), Cc)
+        p1 = torch.full((P1 * 2 * Cc,), float('nan'), device=DEV)
+        k.upsample2x_bwd_tail(gu, g1, acc, y, z, mean, istd, p1)
+        assert torch.equal(g0, g1)
+        ref = sums(p0, P0)
+        assert float((sums(p1, P1) - ref).abs().max()) <= stol * float(ref.abs().max()) + 1e-6
+    assert k.tail_stats_blocks(1000, 96) == 0             # 12 channel groups do not divide 256: the engine keeps the two-pass form
