@@ -96,6 +96,7 @@ _PROTOS = {
     'adn_pack_weights': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     'adn_mx8_quantize': (C.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     'adn_mx8_pack': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    'adn_bn_partials_reduce': (C.c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     'adn_tail_stats_blocks': (c_int64, [c_int64, c_int32]),
     'adn_maxpool2_bwd_tail': (C.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -332,7 +332,7 @@ def _update_again(self, eng):
         return
     K.bn_fwd_finalize(self.part, self.P, self.N, eng.B * o.H * o.W, gamma, beta, bn.eps,
                       0.1 if bn.momentum is None else bn.momentum, rmean, rvar, bn.num_batches_tracked, o.mean, o.istd,
-                      self.scale, self.shift)
+                      self.scale, self.shift, scratch=eng.bn_scratch)
 
 
 ConvBNReLU.update_running_stats_again = _update_again

@@ -664,6 +664,50 @@ extern "C" int adn_bn_bwd_apply_mx8(void* g, const void* z, int64_t pixels, int3
   return ADN_OK;
 }
 
+// Pre-reduction of BatchNorm partial rows for the layers that hold thousands of them (the 256^2 / 512^2 levels of the
+// DoubleConv nets: one row per 128-pixel GEMM tile = 16 384 rows at B = 32, 256^2): the finalize kernels walk the rows with one
+// workgroup per channel (4-byte reads at a 2 C float stride, 17-20 us per launch there).  Here a workgroup owns 32 channels x
+// one slice of rows and reads whole 128-byte row segments; `slices` rows [slices][2][C] go to `out_rows`, which the
+// finalize kernel then sums.  f64 accumulation inside a slice.
+__global__ __launch_bounds__(256) void bn_partials_reduce_kernel(const float* partials, int64_t P, int C, int slices,
+                                                                 float* out_rows) {
+  __shared__ double sh[32][8][8];
+  const int cq = threadIdx.x & 7, rl = threadIdx.x >> 3;            // 8 lanes x 4 channels, 32 row lanes
+  const int c0 = blockIdx.x * 32 + cq * 4;
+  const int64_t R = (P + slices - 1) / slices;
+  const int64_t r0 = (int64_t)blockIdx.y * R;
+  const int64_t r1 = r0 + R < P ? r0 + R : P;
+  double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int64_t r = r0 + rl; r < r1; r += 32) {
+    const f32x4_t x = *reinterpret_cast<const f32x4_t*>(partials + (r * 2 + 0) * C + c0);
+    const f32x4_t y = *reinterpret_cast<const f32x4_t*>(partials + (r * 2 + 1) * C + c0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      a[k] += (double)x[k];
+      a[4 + k] += (double)y[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) sh[rl][cq][k] = a[k];
+  __syncthreads();
+  if (threadIdx.x < 64) {                                           // 8 lanes x 8 values
+    const int q = threadIdx.x >> 3, k = threadIdx.x & 7;
+    double t = 0.0;
+    for (int r = 0; r < 32; ++r) t += sh[r][q][k];
+    out_rows[((int64_t)blockIdx.y * 2 + (k >> 2)) * C + blockIdx.x * 32 + q * 4 + (k & 3)] = (float)t;
+  }
+}
+
+extern "C" int adn_bn_partials_reduce(const float* partials, int64_t P, int32_t C, int32_t slices, float* out_rows,
+                                      void* stream) {
+  ADN_CHECK_ARG(partials && out_rows && P > 0 && C > 0 && C % 32 == 0 && slices > 0 && slices <= 1024,
+                "adn_bn_partials_reduce: bad arguments (C=%d must be a multiple of 32)", C);
+  hipLaunchKernelGGL(bn_partials_reduce_kernel, dim3(C / 32, slices), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     partials, P, C, slices, out_rows);
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}
+
 extern "C" int adn_bn_bwd_finalize(const float* partials, int64_t P, int32_t C, int64_t count, float* dgamma,
                                    float* dbeta, float* coef, void* stream) {
   ADN_CHECK_ARG(partials && P > 0 && C > 0 && count > 0 && coef, "adn_bn_bwd_finalize: bad arguments");

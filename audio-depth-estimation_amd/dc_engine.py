@@ -191,6 +191,10 @@ class ConvBNReLU(Op):
         ws3 = K.wgrad_workspace_bytes(T, B, H, W, N, 0, self.c0, self.c1, c_valid=cv, ks=self.ks)
         self.c_valid = cv
         self._ws = max(ws1, ws2, ws3)
+        # shared scratch of the BatchNorm partial-row pre-reduction (kernels._bn_prereduce): 64 rows x 2 x the widest layer
+        need = K.BN_REDUCE_SLICES * 2 * N
+        if getattr(eng, 'bn_scratch', None) is None or eng.bn_scratch.numel() < need or eng.bn_scratch.device != dev:
+            eng.bn_scratch = torch.empty(max(need, K.BN_REDUCE_SLICES * 2 * 1024), **f32)
 
     def workspace_bytes(self, eng):
         return self._ws
@@ -246,7 +250,7 @@ class ConvBNReLU(Op):
             K.bn_fwd_finalize(self.part, self.P, N, pixels, gamma, beta, bn.eps,
                               BN_MOMENTUM if bn.momentum is None else bn.momentum, rmean, rvar,
                               bn.num_batches_tracked if rmean is not None else None, o.mean, o.istd, self.scale,
-                              self.shift)
+                              self.shift, scratch=eng.bn_scratch)
             if o.want_q8 and N % 32 == 0:             # a consumer is an fp8 conv: its operand copy comes with the output
                 K.bn_act_mx8(o.z, pixels, N, self.scale, self.shift, o.data, o.q8, o.q8s)
                 o.q8_serial = eng.fwd_serial
@@ -275,11 +279,11 @@ class ConvBNReLU(Op):
             K.relu_bwd_stats(G, o.data, o.z, o.mean, o.istd, pixels, N, o.bpart)
         fg = lambda p: eng._flat_slice(eng.flat_g, p)
         if self.padded:
-            K.bn_bwd_finalize(o.bpart, o.bpart_rows, N, pixels, self.dgamma_p, self.dbeta_p, self.coef)
+            K.bn_bwd_finalize(o.bpart, o.bpart_rows, N, pixels, self.dgamma_p, self.dbeta_p, self.coef, scratch=eng.bn_scratch)
             K.pack_rows(self.dgamma_p[:self.n_real], self.n_real, 1, 1, fg(bn.weight))
             K.pack_rows(self.dbeta_p[:self.n_real], self.n_real, 1, 1, fg(bn.bias))
         else:
-            K.bn_bwd_finalize(o.bpart, o.bpart_rows, N, pixels, fg(bn.weight), fg(bn.bias), self.coef)
+            K.bn_bwd_finalize(o.bpart, o.bpart_rows, N, pixels, fg(bn.weight), fg(bn.bias), self.coef, scratch=eng.bn_scratch)
         if self.mx8 and self.need_dgrad:                 # G is now d loss / d z (+ its fp8 copy for the input-gradient GEMM)
             K.bn_bwd_apply_mx8(G, o.z, pixels, N, self.scale, o.mean, o.istd, self.coef, self.g8, self.g8s)
         else:

@@ -286,8 +286,21 @@ def nhwc_to_nchw(src, dst):
     _lib.call('adn_nhwc_to_nchw', ptr(src), ptr(dst), B, Cc, H, W, dtype_code(src.dtype), _stream())
 
 
+BN_REDUCE_ROWS, BN_REDUCE_SLICES = 2048, 64
+
+
+def _bn_prereduce(partials, P, Cc, scratch):
+    """Layers with thousands of partial rows: coalesced pre-reduction to 64 rows in ``scratch`` (f32 [>= 64 * 2 * C])."""
+    if scratch is None or P < BN_REDUCE_ROWS or Cc % 32 != 0 or scratch.numel() < BN_REDUCE_SLICES * 2 * Cc:
+        return partials, P
+    _dev(partials, scratch)
+    _lib.call('adn_bn_partials_reduce', ptr(partials), P, Cc, BN_REDUCE_SLICES, ptr(scratch), _stream())
+    return scratch, BN_REDUCE_SLICES
+
+
 def bn_fwd_finalize(partials, P, Cc, count, gamma, beta, eps, momentum, running_mean, running_var, nbt, mean,
-                    istd, scale, shift):
+                    istd, scale, shift, scratch=None):
+    partials, P = _bn_prereduce(partials, P, Cc, scratch)
     _dev(partials, mean, istd, scale, shift)
     _lib.call('adn_bn_fwd_finalize', ptr(partials), P, Cc, count, ptr(gamma), ptr(beta), eps, momentum,
               ptr(running_mean), ptr(running_var), ptr(nbt), ptr(mean), ptr(istd), ptr(scale), ptr(shift),
@@ -322,7 +335,8 @@ def bn_act(z, pixels, Cc, scale, shift, slope, out_leaky=None, out_relu=None):
               ptr(out_relu), _stream())
 
 
-def bn_bwd_finalize(partials, P, Cc, count, dgamma, dbeta, coef):
+def bn_bwd_finalize(partials, P, Cc, count, dgamma, dbeta, coef, scratch=None):
+    partials, P = _bn_prereduce(partials, P, Cc, scratch)
     _dev(partials, coef)
     _lib.call('adn_bn_bwd_finalize', ptr(partials), P, Cc, count, ptr(dgamma), ptr(dbeta), ptr(coef), _stream())
 

@@ -406,6 +406,9 @@ int adn_bn_act(const void* z, int64_t pixels, int32_t C, int32_t dtype, const fl
                const float* shift, float slope, void* out_leaky, void* out_relu, void* stream);
 /* Backward finalize: partial sums of g and g*xhat -> dgamma, dbeta and c1=sum g/count,
  * c2=sum g*xhat/count (coef[0..C) = c1, coef[C..2C) = c2). */
+/* Pre-reduction of BatchNorm partial rows (forward or backward statistics) [P][2][C] -> [slices][2][C], coalesced, for layers
+ * with thousands of rows; adn_bn_fwd_finalize / adn_bn_bwd_finalize then run on the `slices` rows.  C % 32 == 0. */
+int adn_bn_partials_reduce(const float* partials, int64_t P, int32_t C, int32_t slices, float* out_rows, void* stream);
 int adn_bn_bwd_finalize(const float* partials, int64_t P, int32_t C, int64_t count, float* dgamma,
                         float* dbeta, float* coef, void* stream);
 /* In place: g <- scale * (g - c1 - xhat*c2), xhat = (z-mean)*istd. */

@@ -403,3 +403,33 @@ def test_bn_fused_small_tensor_kernels(dtype, shape):
     k.bn_bwd_apply(g2, z, pixels, C, scale, mean, istd, coef)
     assert rel_err(dg1, dg2) <= 1e-6 and rel_err(db1, db2) <= 1e-6
     assert rel_err(g1, g2) <= TOL_T_OUT[dtype]
+
+
+def test_bn_partials_prereduction():
+    """adn_bn_partials_reduce + finalize on the 64 pre-reduced rows equals the finalize over all rows (f64 sums of the same f32
+    values, re-associated: <= 1e-6 relative on mean / istd), forward and backward form; ragged last slice."""
+    k = K()
+    torch.manual_seed(2)
+    P, Cc, count = 5000, 96, 5000 * 128
+    part = (torch.randn(P, 2, Cc) * 3).abs().to(DEV)                      # [P][2][C]: sum z, sum z^2 (kept positive / consistent)
+    part[:, 1] = part[:, 1] + part[:, 0] ** 2 / 128
+    scratch = torch.full((k.BN_REDUCE_SLICES * 2 * Cc,), float('nan'), device=DEV)
+    gamma, beta = torch.rand(Cc, device=DEV) + 0.5, torch.randn(Cc, device=DEV)
+    outs = []
+    for sc in (None, scratch):
+        mean, istd, scale, shift = [torch.empty(Cc, device=DEV) for _ in range(4)]
+        k.bn_fwd_finalize(part.view(-1), P, Cc, count, gamma, beta, 1e-5, 0.1, None, None, None, mean, istd, scale, shift,
+                          scratch=sc)
+        outs.append((mean, istd, scale, shift))
+    for a, b in zip(*outs):
+        assert float((a - b).abs().max()) <= 1e-6 * float(a.abs().max()) + 1e-9
+    rows = scratch.view(k.BN_REDUCE_SLICES, 2, Cc)
+    R = -(-P // k.BN_REDUCE_SLICES)
+    want = torch.stack([part[s * R:(s + 1) * R].double().sum(0) for s in range(k.BN_REDUCE_SLICES)]).float()
+    assert float((rows - want).abs().max()) <= 1e-6 * float(want.abs().max())
+    coefs = []
+    for sc in (None, scratch):
+        dg, db, coef = torch.empty(Cc, device=DEV), torch.empty(Cc, device=DEV), torch.empty(2 * Cc, device=DEV)
+        k.bn_bwd_finalize(part.view(-1), P, Cc, count, dg, db, coef, scratch=sc)
+        coefs.append(torch.cat([dg, db, coef]))
+    assert float((coefs[0] - coefs[1]).abs().max()) <= 1e-6 * float(coefs[0].abs().max())
