@@ -27,7 +27,7 @@ namespace {
 //                                               zero-record descriptor (every load dropped, zeros in LDS; wrong results)
 //   ADN_IGEMM_SKIP                              timing-only builds: bit 0 / 1 = the operand's LDS-DMA is not issued at all
 struct Tune {
-  int bm = 0, bn = 0, ns = 0, noa = 0, nob = 0, skip = 0, patch = 1, tall = 1;
+  int bm = 0, bn = 0, ns = 0, noa = 0, nob = 0, skip = 0, patch = 1, tall = 1, pair = 1;
 };
 const Tune& tune() {
   static Tune t;
@@ -41,6 +41,7 @@ const Tune& tune() {
     if (const char* e = getenv("ADN_IGEMM_SKIP")) t.skip = atoi(e);
     if (const char* e = getenv("ADN_IGEMM_PATCH")) t.patch = atoi(e);
     if (const char* e = getenv("ADN_IGEMM_TALL")) t.tall = atoi(e);
+    if (const char* e = getenv("ADN_IGEMM_PAIR")) t.pair = atoi(e);
   });
   return t;
 }
@@ -502,7 +503,10 @@ __global__ __launch_bounds__(BM * NWN, 2) void igemm_mfma_kernel(KParams p) {
 // each).  With the 2 x 2 wave grid a 64-column tile leaves every wave a 64 x 32 sub-tile: 12 ds_read_b128 per 16 MFMAs, and
 // the two waves of a row pair read the same A fragments -- LDS bandwidth, not the matrix pipe, bounds the step (PMC:
 // SQ_WAIT_INST_LDS 4.7x the 128-column variant).  64 x 64 per wave is 8 reads per 16 MFMAs with no shared fragments.
-template <int BN, int GEOM, bool TALL = false, bool PRE = true>
+// PAIR (S2 / T2, 8 x 8 small-grid images -- the Hs = 8 level of unet_256): a tile is two whole images side by side (8 rows x
+// [8 columns of image 2t | 8 columns of image 2t + 1]); every patch plane holds the two images' 9 columns back to back (18
+// columns), so the only change for the fragment reads is +1 LDS pixel for the second image's output columns.
+template <int BN, int GEOM, bool TALL = false, bool PRE = true, bool PAIR = false>
 __global__ __launch_bounds__(256, 2) void igemm_patch_kernel(KParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef uint16_t T;
@@ -510,7 +514,7 @@ __global__ __launch_bounds__(256, 2) void igemm_patch_kernel(KParams p) {
   constexpr int BM = TH * TW, NWN = TALL ? 1 : 2, NTHR = 256;
   constexpr int WN = BN / NWN, NT = WN / 16, MT = 4;
   constexpr bool S2 = GEOM == ADN_GEMM_S2, S1 = GEOM == ADN_GEMM_S1;
-  constexpr int MW = S1 ? TW + 2 : TW + 1;                    // patch columns per plane (S1: 3 x 3 window, 18 columns)
+  constexpr int MW = (S1 || PAIR) ? TW + 2 : TW + 1;          // patch columns per plane (S1: 3 x 3 window, 18 columns; PAIR: 9 + 9)
   constexpr int SEG_PIX = S2 ? 2 * (TH + 1) * MW : (S1 ? (TH + 2) * MW : (TH + 1) * MW);   // 306 / 180 / 153 pixels
   constexpr int SEG_STEPS = S2 ? 4 : (S1 ? 3 : 2);            // K-steps served by one segment
   constexpr int TPS = S1 ? 3 : 2;                             // taps per K-step (S1: one kernel row)
@@ -540,9 +544,17 @@ __global__ __launch_bounds__(256, 2) void igemm_patch_kernel(KParams p) {
   const int Hs = p.Hs, Ws = p.Ws, Hl = 2 * Hs, Wl = 2 * Ws;
   const int Cin = p.C0 + p.C1;
   // tile -> (image, first output row, first output column) on the small grid
-  const int tpr = Ws / TW, tpi = (Hs / TH) * tpr;
-  const int tb = tile_m / tpi, trem = tile_m - tb * tpi;
-  const int oy0 = (trem / tpr) * TH, ox0 = (trem % tpr) * TW;
+  int tb, oy0, ox0;
+  if constexpr (PAIR) {
+    tb = 2 * tile_m;                       // first image of the pair; the tile is both images in full
+    oy0 = ox0 = 0;
+  } else {
+    const int tpr = Ws / TW, tpi = (Hs / TH) * tpr;
+    tb = tile_m / tpi;
+    const int trem = tile_m - tb * tpi;
+    oy0 = (trem / tpr) * TH;
+    ox0 = (trem % tpr) * TW;
+  }
   // gathered image: S2 gathers from the large grid (2Hs x 2Ws), T2 from the small grid
   const int Hg = S2 ? Hl : Hs, Wg = S2 ? Wl : Ws;        // (S1 and T2 gather from the small grid)
   const int ymin = (S2 || S1) ? 0 : (ph == 0 ? -1 : 0), xmin = (S2 || S1) ? 0 : (pw == 0 ? -1 : 0);
@@ -557,21 +569,32 @@ __global__ __launch_bounds__(256, 2) void igemm_patch_kernel(KParams p) {
     const int q = 16 * (wave + 4 * k) + (lane >> 2);
     int iy, ix;
     bool ok0, ok1;
+    int img = 0;                             // PAIR: which image of the pair this patch column belongs to
     if constexpr (S2) {
       const int par = q / ((TH + 1) * MW), rem = q - par * ((TH + 1) * MW);
-      const int hr = rem / MW, m = rem - hr * MW;
+      const int hr = rem / MW;
+      int m = rem - hr * MW;
+      if constexpr (PAIR) {
+        img = m >= 9 ? 1 : 0;
+        m -= 9 * img;
+      }
       iy = 2 * oy0 - 1 + 2 * hr;             // row of parity 0; parity 1 is the next row
       ix = 2 * ox0 - 1 + 2 * m + par;
       const bool okx = (unsigned)ix < (unsigned)Wg && q < SEG_PIX;
       ok0 = okx && (unsigned)iy < (unsigned)Hg;
       ok1 = okx && (unsigned)(iy + 1) < (unsigned)Hg;
     } else {
-      const int hr = q / MW, m = q - hr * MW;
+      const int hr = q / MW;
+      int m = q - hr * MW;
+      if constexpr (PAIR) {
+        img = m >= 9 ? 1 : 0;
+        m -= 9 * img;
+      }
       iy = oy0 + hr + (S1 ? -1 : ymin);
       ix = ox0 + m + (S1 ? -1 : xmin);
       ok0 = ok1 = (unsigned)ix < (unsigned)Wg && (unsigned)iy < (unsigned)Hg && q < SEG_PIX;
     }
-    ppix[k] = (unsigned)((tb * Hg + iy) * Wg + ix + bshift);
+    ppix[k] = (unsigned)(((tb + img) * Hg + iy) * Wg + ix + bshift);
     pmask |= (ok0 ? 1u : 0u) << (2 * k) | (ok1 ? 2u : 0u) << (2 * k);
   }
   // ---- weight loader geometry: piece pid = wave + 4k of a step's [2][BN][64 B] tile ----
@@ -648,9 +671,11 @@ __global__ __launch_bounds__(256, 2) void igemm_patch_kernel(KParams p) {
   const int e_cg = tid % CPR, e_rsub = tid / CPR;
   const int e_n0 = tile_n * BN + e_cg * 8;
   auto row_op = [&](int row) -> int64_t {       // output pixel index of tile row `row` (row = oyl * 16 + oxl)
-    const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
-    if constexpr (S2 || S1) return ((int64_t)tb * Hs + oy) * Ws + ox;
-    else return ((int64_t)tb * Hl + 2 * oy + ph) * Wl + 2 * ox + pw;
+    const int oy = oy0 + (row >> 4);
+    const int ox = PAIR ? (row & 7) : ox0 + (row & 15);
+    const int ib = PAIR ? tb + ((row >> 3) & 1) : tb;
+    if constexpr (S2 || S1) return ((int64_t)ib * Hs + oy) * Ws + ox;
+    else return ((int64_t)ib * Hl + 2 * oy + ph) * Wl + 2 * ox + pw;
   };
   // (S2 = dgrad of a transposed conv never accumulates in the U-Net: its running-gradient chunk is not kept in registers
   //  -- 32 VGPRs that made the 128-column variant spill -- but read in the epilogue if a caller asks for it)
@@ -683,7 +708,7 @@ __global__ __launch_bounds__(256, 2) void igemm_patch_kernel(KParams p) {
 
   const int frow = lane & 15, fq = lane >> 4;
   // fragment pixel base of this lane's M-tile i: (oyl = wm*4 + i) * MW + frow
-  const int qb0 = wm * 4 * MW + frow;
+  const int qb0 = wm * 4 * MW + frow + (PAIR ? (frow >> 3) : 0);   // (PAIR: the second image's columns sit one LDS pixel further)
 
   int s = 0;
   for (int sg = 0; sg < nseg; ++sg) {
@@ -909,6 +934,7 @@ struct Plan {
   bool wide;
   bool patch;       // patch-staged kernel (bf16, wide, unsplit, image 8 x 16 tileable)
   bool tall;        // its 16 x 16-pixel, 4 x 1-wave form (64 output columns, T2 / S1, image 16 x 16 tileable)
+  bool pair;        // its two-images-per-tile form (S2 / T2, 8 x 8 small-grid images, 128 output columns, unsplit)
   int wstride;
   int rb;
   int bm;
@@ -939,7 +965,7 @@ bool make_plan(const AdnIgemmDesc* d, Plan* pl) {
   const bool aligned = (pl->wide || narrow_ok) && (d->N % 64 == 0) && (d->seg[0].channels % 64 == 0) &&
                        (d->seg[1].channels % 64 == 0);
   pl->mfma = aligned;
-  pl->patch = pl->tall = false;
+  pl->patch = pl->tall = pl->pair = false;
   if (!aligned) {
     pl->bn = 0;
     pl->nsplit = 1;
@@ -982,7 +1008,19 @@ bool make_plan(const AdnIgemmDesc* d, Plan* pl) {
   // enough tiles that no split-K is wanted (ADN_IGEMM_PATCH=0 switches it off)
   pl->patch = d->dtype == ADN_BF16 && pl->wide && ns == 1 && (d->geom != ADN_GEMM_S1 || d->ks == 3) && d->Hs % 8 == 0 &&
               d->Ws % 16 == 0 && tn.patch != 0;
-  pl->tall = pl->patch && pl->bn == 64 && d->geom != ADN_GEMM_S2 && d->Hs % 16 == 0 && tn.tall != 0 &&
+  // two 8 x 8 images per tile: replaces the split-K launch + reduce of that level by one unsplit patch launch
+  // (T2 only: the S2 form -- D4 dgrad, 128 workgroups x 128 K-steps -- measured 99 us against 40 us for split-K + reduce)
+  pl->pair = d->dtype == ADN_BF16 && pl->wide && d->geom == ADN_GEMM_T2 && d->Hs == 8 && d->Ws == 8 && d->B % 2 == 0 &&
+             d->N % 128 == 0 && tn.pair != 0 && tn.patch != 0 &&
+             msmall / 128 * (d->N / 128) * pl->phases >= 128;      // (64 workgroups with a 128-step K loop lose to split-K: L4 forward)
+  if (pl->pair) {
+    pl->patch = true;
+    pl->bn = 128;
+    pl->tiles_n = d->N / 128;
+    ns = 1;
+    pl->nsplit = 1;
+  }
+  pl->tall = !pl->pair && pl->patch && pl->bn == 64 && d->geom != ADN_GEMM_S2 && d->Hs % 16 == 0 && tn.tall != 0 &&
              msmall / 256 * pl->tiles_n * pl->phases >= 512;
   if (pl->patch) {
     pl->bm = pl->tall ? 256 : 128;
@@ -1026,20 +1064,23 @@ void dispatch_mfma(const KParams& kp, const Plan& pl, hipStream_t st) {
   else dispatch_mfma2<T, GEOM, false>(kp, pl, st);
 }
 
-template <int BN, int GEOM, bool TALL = false, bool PRE = true>
+template <int BN, int GEOM, bool TALL = false, bool PRE = true, bool PAIR = false>
 void launch_patch1(const KParams& kp, const Plan& pl, hipStream_t st) {
   constexpr bool S2 = GEOM == ADN_GEMM_S2, S1 = GEOM == ADN_GEMM_S1;
   constexpr int TH = TALL ? 16 : 8;
-  constexpr int ppieces = ((S2 ? 2 * (TH + 1) * 17 : (S1 ? (TH + 2) * 18 : (TH + 1) * 17)) + 15) / 16;
+  constexpr int MWc = PAIR ? 18 : 17;
+  constexpr int ppieces = ((S2 ? 2 * (TH + 1) * MWc : (S1 ? (TH + 2) * 18 : (TH + 1) * MWc)) + 15) / 16;
   constexpr int stage = 2 * ppieces * 1024 + 2 * (S1 ? 3 : 2) * BN * 64;
   constexpr int epil = TH * 16 * (BN + 4) * 4;
   constexpr int lds = stage > epil ? stage : epil;
-  ADN_SET_LDS_ONCE(lds, &igemm_patch_kernel<BN, GEOM, TALL, PRE>);
+  ADN_SET_LDS_ONCE(lds, &igemm_patch_kernel<BN, GEOM, TALL, PRE, PAIR>);
   dim3 grid(pl.tiles_m * pl.tiles_n * pl.phases, 1, 1);
-  hipLaunchKernelGGL((igemm_patch_kernel<BN, GEOM, TALL, PRE>), grid, dim3(256), lds, st, kp);
+  hipLaunchKernelGGL((igemm_patch_kernel<BN, GEOM, TALL, PRE, PAIR>), grid, dim3(256), lds, st, kp);
 }
 inline void launch_patch(const KParams& kp, const Plan& pl, int geom, hipStream_t st) {
-  if (geom == ADN_GEMM_S2) {
+  if (pl.pair) {                 // 8 x 8 images, two per tile (every unet_256 layer of that level has >= 128 output columns)
+    launch_patch1<128, ADN_GEMM_T2, false, true, true>(kp, pl, st);
+  } else if (geom == ADN_GEMM_S2) {
     if (pl.bn == 128) launch_patch1<128, ADN_GEMM_S2>(kp, pl, st);
     else launch_patch1<64, ADN_GEMM_S2>(kp, pl, st);
   } else if (geom == ADN_GEMM_T2) {

@@ -69,6 +69,8 @@ SHAPES = [
     (16, 64, 0, 128, 64),    # MFMA, 256-row tiles / 8 waves / 3-stage LDS-DMA ring (S2: 256 tiles)
     (16, 64, 64, 64, 32),    # same for T2 (64 tiles x 4 phases), BN=64
     (8, 64, 64, 64, 64),     # T2: 128 tiles of 16 x 16 pixels x 4 phases -> the tall 4 x 1-wave patch kernel (BN = 64)
+    (4, 128, 0, 256, 8),     # 8 x 8 small-grid images: two images per patch tile (PAIR form), S2 and T2
+    (6, 64, 64, 128, 8),     # PAIR form with two gathered sources, three image pairs
     (2, 6, 0, 10, 4),        # generic direct path
     (1, 3, 5, 1, 5),         # generic, two sources, single output channel, odd size
 ]
