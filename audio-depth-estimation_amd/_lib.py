@@ -53,7 +53,7 @@ class AdnWgradDesc(C.Structure):
         ('plain0', c_void_p), ('plain1', c_void_p), ('R0', c_int32), ('R1', c_int32),
         ('gath0', c_void_p), ('gath1', c_void_p), ('C0', c_int32), ('C1', c_int32),
         ('dw', c_void_p), ('workspace', c_void_p), ('workspace_bytes', c_int64), ('c_valid', c_int32),
-        ('geom', c_int32), ('ks', c_int32),
+        ('geom', c_int32), ('ks', c_int32), ('sq_partials', c_void_p),
     ]
 
 
@@ -93,6 +93,7 @@ _PROTOS = {
     'adn_igemm': (C.c_int, [C.POINTER(AdnIgemmDesc), c_void_p]),
     'adn_wgrad_workspace_bytes': (c_int64, [C.POINTER(AdnWgradDesc)]),
     'adn_wgrad': (C.c_int, [C.POINTER(AdnWgradDesc), c_void_p]),
+    'adn_wgrad_sq_count': (c_int32, [C.POINTER(AdnWgradDesc)]),
     'adn_pack_weights': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     'adn_mx8_quantize': (C.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     'adn_mx8_pack': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
@@ -197,6 +198,8 @@ _PROTOS = {
     'adn_sum_to_scalar': (C.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
     'adn_grad_norm': (C.c_int, [c_void_p, c_int64, c_float, c_void_p, c_void_p, c_int64, c_void_p]),
     'adn_grad_norm_workspace_bytes': (c_int64, [c_int64]),
+    'adn_grad_norm_ranges': (C.c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_float, c_void_p, c_void_p,
+                                       c_int64, c_void_p]),
     'adn_optimizer_step': (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_float,
                                      c_float, c_float, c_float, c_int32, c_void_p, c_void_p, c_void_p]),
     'adn_pack_t2_multi': (C.c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p]),

@@ -176,6 +176,41 @@ __global__ __launch_bounds__(256) void grad_norm_final_kernel(const double* part
   }
 }
 
+// one workgroup per (offset, length) row: length <= 8192 elements, offset and length multiples of 4
+__global__ __launch_bounds__(256) void sqsum_ranges_kernel(const float* g, const int64_t* ranges, double* partials) {
+  __shared__ double sh[4];
+  const int64_t off = ranges[2 * blockIdx.x], len = ranges[2 * blockIdx.x + 1];
+  const f32x4_t* g4 = reinterpret_cast<const f32x4_t*>(g + off);
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < (len >> 2); i += 256) {
+    const f32x4_t v = g4[i];
+    s += (double)(v[0] * v[0] + v[1] * v[1]) + (double)(v[2] * v[2] + v[3] * v[3]);
+  }
+  s = block_sum_d(s, sh);
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+// total norm / clip coefficient from two lists of partial sums of squares
+__global__ __launch_bounds__(1024) void grad_norm_final2_kernel(const double* a, int na, const double* b, int nb,
+                                                                float max_norm, double* state) {
+  __shared__ double sh[16];
+  double v = 0.0;
+  for (int i = threadIdx.x; i < na; i += 1024) v += a[i];
+  for (int i = threadIdx.x; i < nb; i += 1024) v += b[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += sh[w];
+    const double total = sqrt(t);
+    double coef = (double)max_norm / (total + 1e-6);   // torch clip_grad_norm_: clamp(max_norm/(total+1e-6), max=1)
+    if (coef > 1.0) coef = 1.0;
+    state[3] = total;
+    state[4] = coef;
+  }
+}
+
 __global__ void optimizer_advance_kernel(double* state, double beta1, double beta2) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     const double t = state[0] + 1.0;
@@ -342,6 +377,27 @@ extern "C" int adn_grad_norm(const float* grads, int64_t n, float max_norm, doub
   hipLaunchKernelGGL(sqsum_partial_kernel, dim3(nb), dim3(256), 0, st, grads, n, part);
   ADN_CHECK_LAUNCH();
   hipLaunchKernelGGL(grad_norm_final_kernel, dim3(1), dim3(256), 0, st, part, (int)nb, max_norm, state);
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}
+
+extern "C" int adn_grad_norm_ranges(const float* grads, const int64_t* ranges, int32_t n_ranges, const double* extra,
+                                    int32_t n_extra, float max_norm, double* state, void* workspace,
+                                    int64_t workspace_bytes, void* stream) {
+  ADN_CHECK_ARG(grads && state && n_ranges >= 0 && n_extra >= 0 && n_ranges + n_extra > 0,
+                "adn_grad_norm_ranges: bad arguments");
+  ADN_CHECK_ARG(n_ranges == 0 || (ranges && workspace && workspace_bytes >= (int64_t)n_ranges * 8),
+                "adn_grad_norm_ranges: workspace too small");
+  ADN_CHECK_ARG(n_extra == 0 || extra, "adn_grad_norm_ranges: null partial sums");
+  ADN_CHECK_ARG((reinterpret_cast<uintptr_t>(grads) & 15) == 0, "adn_grad_norm_ranges: grads must be 16-byte aligned");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  double* part = reinterpret_cast<double*>(workspace);
+  if (n_ranges > 0) {
+    hipLaunchKernelGGL(sqsum_ranges_kernel, dim3((unsigned)n_ranges), dim3(256), 0, st, grads, ranges, part);
+    ADN_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(grad_norm_final2_kernel, dim3(1), dim3(1024), 0, st, part, (int)n_ranges, extra, (int)n_extra,
+                     max_norm, state);
   ADN_CHECK_LAUNCH();
   return ADN_OK;
 }

@@ -25,7 +25,17 @@ struct WParams {
   float* out;     // dW or slab base
   int64_t out_elems;
   int c_valid;    // gathered channels actually stored (compact [R][16][c_valid]); == C0+C1 normally
+  double* sq;     // optional: per-workgroup sum of dW^2 (only with nsplit == 1 and c_valid == C: this kernel writes the final dW)
 };
+
+// sum over the 256 threads of a workgroup, result valid in thread 0 (sh: 4 doubles)
+__device__ __forceinline__ double wg4_block_sum_d(double v, double* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
 
 // 128 zero bytes: LDS-DMA source for rows beyond M / padded taps / the upper half of an R=64 tile
 __device__ u32x4_t adn_wg4_zero_page[8];
@@ -290,13 +300,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
   const int R = p.R0 + p.R1;
   if (p.c_valid == C) {
     const int64_t ldo = (int64_t)16 * C;
+    double sq = 0.0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       const int row = r0 + 8 * k;
       if (tile_r * 128 + row < R) {
         const f32x4_t v = *reinterpret_cast<const f32x4_t*>(ct + row * LDC + cq * 4);
         *reinterpret_cast<f32x4_t*>(out + (int64_t)(tile_r * 128 + row) * ldo + tile_c * 128 + cq * 4) = v;
+        sq += (double)(v[0] * v[0] + v[1] * v[1]) + (double)(v[2] * v[2] + v[3] * v[3]);   // as sqsum_partial_kernel
       }
+    }
+    if (p.sq) {     // uniform: the final dW leaves this kernel, its share of the gradient norm rides along
+      __syncthreads();                              // everyone is done with the staged tile: reuse its first bytes
+      sq = wg4_block_sum_d(sq, reinterpret_cast<double*>(smem));
+      if (tid == 0) p.sq[lid] = sq;
     }
   } else {
     // zero-padded gathered channels (edge layers): keep only c < c_valid, compact [R][16][c_valid]
@@ -348,10 +365,11 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(WParams p, int pix_pe
   p.out[(int64_t)split * p.out_elems + e] = acc;
 }
 
-__global__ __launch_bounds__(256) void slab_sum_kernel(const float* slab, float* out, int64_t n, int nsplit) {
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* slab, float* out, int64_t n, int nsplit, double* sq) {
   // n is a multiple of 4 (R*16*c with R % 64 == 0); 4 independent accumulator chains hide the load latency
   const int64_t n4 = n >> 2;
   const f32x4_t* s4 = reinterpret_cast<const f32x4_t*>(slab);
+  double sqs = 0.0;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (int64_t)gridDim.x * 256) {
     f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
     int s = 0;
@@ -362,14 +380,29 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* slab, float*
       a3 += s4[(int64_t)(s + 3) * n4 + e];
     }
     for (; s < nsplit; ++s) a0 += s4[(int64_t)s * n4 + e];
-    reinterpret_cast<f32x4_t*>(out)[e] = (a0 + a1) + (a2 + a3);
+    const f32x4_t v = (a0 + a1) + (a2 + a3);
+    reinterpret_cast<f32x4_t*>(out)[e] = v;
+    sqs += (double)(v[0] * v[0] + v[1] * v[1]) + (double)(v[2] * v[2] + v[3] * v[3]);      // as sqsum_partial_kernel
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const int64_t e = (n4 << 2) + threadIdx.x;
     float v = 0.f;
     for (int s = 0; s < nsplit; ++s) v += slab[(int64_t)s * n + e];
     out[e] = v;
+    sqs += (double)v * v;
   }
+  if (sq) {         // uniform: this launch writes the final dW, its share of the gradient norm rides along
+    __shared__ double sh[4];
+    sqs = wg4_block_sum_d(sqs, sh);
+    if (threadIdx.x == 0) sq[blockIdx.x] = sqs;
+  }
+}
+
+// workgroups of the slab sum: enough to stream at the HBM rate; fewer when every workgroup leaves a norm partial behind
+inline int64_t slab_sum_blocks(int64_t out_elems, bool sq) {
+  int64_t blocks = adn_cdiv(adn_cdiv(out_elems, 4), 256);
+  const int64_t cap = sq ? 1024 : 4096;
+  return blocks > cap ? cap : blocks;
 }
 
 struct WPlan {
@@ -442,6 +475,7 @@ int wrun(const AdnWgradDesc* d, const WPlan& pl, hipStream_t st) {
   p.out = pl.nsplit > 1 ? reinterpret_cast<float*>(d->workspace) : d->dw;
   p.out_elems = pl.out_elems;
   p.c_valid = d->c_valid > 0 ? d->c_valid : d->C0 + d->C1;
+  p.sq = (pl.mfma && pl.nsplit == 1 && p.c_valid == d->C0 + d->C1) ? d->sq_partials : nullptr;
   if (pl.mfma) {
     constexpr int BKP = sizeof(T) == 2 ? 64 : 32;
     constexpr int stage = 4 * BKP * 128 * (int)sizeof(T);
@@ -459,10 +493,9 @@ int wrun(const AdnWgradDesc* d, const WPlan& pl, hipStream_t st) {
   }
   ADN_CHECK_LAUNCH();
   if (pl.nsplit > 1) {
-    int64_t blocks = adn_cdiv(adn_cdiv(pl.out_elems, 4), 256);
-    if (blocks > 4096) blocks = 4096;
+    const int64_t blocks = slab_sum_blocks(pl.out_elems, d->sq_partials != nullptr);
     hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, st,
-                       reinterpret_cast<const float*>(d->workspace), d->dw, pl.out_elems, pl.nsplit);
+                       reinterpret_cast<const float*>(d->workspace), d->dw, pl.out_elems, pl.nsplit, d->sq_partials);
     ADN_CHECK_LAUNCH();
   }
   return ADN_OK;
@@ -485,6 +518,22 @@ int64_t adn_wgrad_k4_workspace_bytes(const AdnWgradDesc* d) {
   return pl.slab_bytes;
 }
 
+// doubles adn_wgrad_k4 leaves in d->sq_partials: one per workgroup of the launch that writes the final dW
+int32_t adn_wgrad_k4_sq_count(const AdnWgradDesc* d) {
+  if (wvalidate(d) != ADN_OK) return 0;
+  {
+    int ns;
+    int64_t oe;
+    if (adn_wgrad_k4p_plan(d, &ns, &oe)) return ns > 1 ? (int32_t)slab_sum_blocks(oe, true) : 0;
+  }
+  WPlan pl;
+  make_wplan(d, &pl);
+  if (pl.nsplit > 1) return (int32_t)slab_sum_blocks(pl.out_elems, true);
+  const int cv = d->c_valid > 0 ? d->c_valid : d->C0 + d->C1;
+  if (pl.mfma && cv == d->C0 + d->C1) return pl.tiles_r * pl.tiles_c;
+  return 0;
+}
+
 int adn_wgrad_k4(const AdnWgradDesc* d, void* stream) {
   int rc = wvalidate(d);
   if (rc != ADN_OK) return rc;
@@ -498,10 +547,9 @@ int adn_wgrad_k4(const AdnWgradDesc* d, void* stream) {
       rc = adn_wgrad_k4p_launch(d, ns, oe, stream);
       if (rc != ADN_OK) return rc;
       if (ns > 1) {
-        int64_t blocks = adn_cdiv(adn_cdiv(oe, 4), 256);
-        if (blocks > 4096) blocks = 4096;
+        const int64_t blocks = slab_sum_blocks(oe, d->sq_partials != nullptr);
         hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                           reinterpret_cast<const float*>(d->workspace), d->dw, oe, ns);
+                           reinterpret_cast<const float*>(d->workspace), d->dw, oe, ns, d->sq_partials);
         ADN_CHECK_LAUNCH();
       }
       return ADN_OK;

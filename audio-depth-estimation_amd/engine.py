@@ -194,6 +194,7 @@ class UNetEngine(FlatParamEngine):
                 w = lv[wk].weight
                 o = lv[wk + '_t2_off']
                 lv[wk + '_t2'] = self.t2_all[o:o + 16 * w.shape[0] * w.shape[1]]
+        self._prepare_fused_norm(B, dev)
         self.t2_table = torch.tensor(rows, dtype=torch.int64, device=dev)
         self.t2_layers, self.t2_blocks = len(rows), blk
         self.workspace = torch.empty(ws_bytes // 4 + 4, **f32)
@@ -201,6 +202,46 @@ class UNetEngine(FlatParamEngine):
         self.weights_dirty = True
         self._shape_key = key
         self.B = B
+
+    # ------------------------------------------------------------------ fused gradient norm
+    supports_fused_norm = True
+    NORM_ROW = 8192          # elements per row of adn_grad_norm_ranges
+
+    def _prepare_fused_norm(self, B, dev):
+        """clip_grad_norm_ (train.py:689) without a pass over the 54 M-element gradient: the kernel that writes a
+        conv layer's final dW leaves partial sums of dW^2 in ``sq_all`` (AdnWgradDesc.sq_partials); the parameters
+        without such a kernel (BatchNorm affine, bias, the thin edge layers) are covered by ``norm_ranges``."""
+        T = self.dtype
+        self.sq_all = self.norm_ranges = None
+        if os.environ.get('ADN_NO_FUSED_NORM'):
+            return
+        counts, covered = [], set()
+        for i, lv in enumerate(self.levels):
+            edge0 = i == 0 and self.edge_path
+            hs, wsz = lv['hs'], lv['ws']
+            c_up0, c_up1 = lv['cd_out'], lv['cu_in'] - lv['cd_out']
+            nd = 0 if edge0 else K.wgrad_sq_count(T, B, hs, wsz, lv['cd_out'], 0, lv['down_ypad'], 0,
+                                                  lv['cd_in'] if lv['down_ypad'] != lv['cd_in'] else 0)
+            nu = 0 if edge0 else K.wgrad_sq_count(T, B, hs, wsz, c_up0, c_up1, lv['up_ypad'], 0,
+                                                  lv['cu_out'] if lv['up_ypad'] != lv['cu_out'] else 0)
+            for wk, cnt in (('down', nd), ('up', nu)):
+                counts.append((lv, wk, cnt))
+                if cnt:
+                    covered.add(id(lv[wk].weight))
+        rows = []
+        for p, off, numel in self.param_meta:
+            if id(p) in covered:
+                continue
+            for o in range(0, numel, self.NORM_ROW):
+                rows.append([off + o, (min(self.NORM_ROW, numel - o) + 3) // 4 * 4])   # the tail reads zero padding
+        if not covered or len(rows) > 1024:
+            return
+        self.sq_all = torch.zeros(sum(c for _, _, c in counts), dtype=torch.float64, device=dev)
+        o = 0
+        for lv, wk, cnt in counts:
+            lv[wk + '_sq'] = self.sq_all[o:o + cnt] if cnt else None
+            o += cnt
+        self.norm_ranges = torch.tensor(rows, dtype=torch.int64, device=dev).view(-1, 2) if rows else None
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, training):
@@ -304,9 +345,11 @@ class UNetEngine(FlatParamEngine):
             off = self.offset[id(param)]
             _lib.record_py(lambda: self.on_grad_ready(off))
 
-    def backward(self, gout):
-        """gout: d loss / d output, f32 [B, Cout, H, W].  Fills flat_g (all parameters)."""
+    def backward(self, gout, fused_norm=False):
+        """gout: d loss / d output, f32 [B, Cout, H, W].  Fills flat_g (all parameters); with ``fused_norm`` also
+        ``sq_all`` (see _prepare_fused_norm)."""
         T, B, n, L, ws = self.dtype, self.B, self.n, self.levels, self.workspace
+        fused_norm = fused_norm and self.sq_all is not None
         l0 = L[0]
         if l0['cu_out'] != 1:
             raise NotImplementedError('backward is implemented for output_nc == 1 (the depth map)')
@@ -337,7 +380,8 @@ class UNetEngine(FlatParamEngine):
                 K.d0_dgrad(dz, self._flat_slice(self.flat_p, lv['up'].weight), B, hs, wsz, segs[0], segs[1])
                 continue
             K.wgrad(T, B, hs, wsz, in0, in1, dz, None, self._flat_slice(self.flat_g, lv['up'].weight), ws,
-                    c_valid=lv['cu_out'] if (i == 0 and self.cout_pad != lv['cu_out']) else 0)
+                    c_valid=lv['cu_out'] if (i == 0 and self.cout_pad != lv['cu_out']) else 0,
+                    sq=lv['up_sq'] if fused_norm else None)
             self._ready(lv['up'].weight)
             K.igemm(T, GEMM_S2, B, hs, wsz, dz, None, lv['up_s2'], lv['cu_in'], EPI_BWD, segs, ws,
                     algo_c=lv['cu_out'])
@@ -354,7 +398,8 @@ class UNetEngine(FlatParamEngine):
                 K.thin_wgrad(self._x_in, lv['Gd'], None, B, hs, wsz, self._flat_slice(self.flat_g, lv['down'].weight), ws)
             else:
                 K.wgrad(T, B, hs, wsz, lv['Gd'], None, src, None, self._flat_slice(self.flat_g, lv['down'].weight), ws,
-                        c_valid=lv['cd_in'] if (i == 0 and self.cin_pad != lv['cd_in']) else 0)
+                        c_valid=lv['cd_in'] if (i == 0 and self.cin_pad != lv['cd_in']) else 0,
+                        sq=lv['down_sq'] if fused_norm else None)
             self._ready(lv['down'].weight)
             if i > 0:
                 pv = L[i - 1]
@@ -596,10 +641,19 @@ class FusedTrainer:
                           self.silog_weight, self.silog_lambda, self.loss, self.gout)
         if self.ddp is not None:
             _lib.record_py(self.ddp.begin_backward)
-        eng.backward(self.gout)
+        # single process: the weight-gradient kernels leave their share of the total norm behind (no pass over flat_g);
+        # under the reducer the norm is that of the all-reduced gradients, taken afterwards
+        fused = (self.clip_norm is not None and self.ddp is None and getattr(eng, 'supports_fused_norm', False)
+                 and eng.sq_all is not None)
+        if fused:
+            eng.backward(self.gout, fused_norm=True)
+        else:
+            eng.backward(self.gout)
         if self.ddp is not None:
             _lib.record_py(self.ddp.finish)
-        if self.clip_norm is not None:
+        if fused:
+            K.grad_norm_ranges(eng.flat_g, eng.norm_ranges, eng.sq_all, float(self.clip_norm), self.state, self.norm_ws)
+        elif self.clip_norm is not None:
             K.grad_norm(eng.flat_g, float(self.clip_norm), self.state, self.norm_ws)
         K.optimizer_step(eng.flat_p, eng.flat_g, self.exp_avg, self.exp_avg_sq, self.opt_kind, self.lr,
                          self.betas[0], self.betas[1], self.eps, self.weight_decay, self.clip_norm is not None,

@@ -16,7 +16,7 @@ from ._lib import (ADN_BF16, ADN_F32, EPI_ACT, EPI_ADD, EPI_BWD, EPI_FINAL, EPI_
 
 __all__ = ['dtype_code', 'Seg', 'igemm', 'igemm_query', 'wgrad', 'wgrad_workspace_bytes', 'pack_weights',
            'nchw_to_nhwc', 'nhwc_to_nchw', 'bn_fwd_finalize', 'bn_eval_affine', 'bn_act', 'bn_bwd_finalize',
-           'bn_bwd_apply', 'loss_stats', 'loss_finish', 'final_act_bwd', 'sum_to_scalar', 'grad_norm',
+           'bn_bwd_apply', 'loss_stats', 'loss_finish', 'final_act_bwd', 'sum_to_scalar', 'grad_norm', 'grad_norm_ranges', 'wgrad_sq_count',
            'optimizer_step', 'compute_errors', 'frontend', 'convt_n1_forward', 'convt_n1_workspace_bytes']
 
 
@@ -163,9 +163,27 @@ def wgrad_workspace_bytes(dtype, B, Hs, Ws, R0, R1, C0, C1, c_valid=0, ks=0):
     return n
 
 
-def wgrad(dtype, B, Hs, Ws, plain0, plain1, gath0, gath1, dw, workspace=None, c_valid=0, ks=0):
-    """ks=0: the k4 s2 p1 pair (gathered tensor on the 2x grid); ks in {1,3}: stride-1 ks x ks conv (same grid)."""
+def wgrad_sq_count(dtype, B, Hs, Ws, R0, R1, C0, C1, c_valid=0, ks=0):
+    """Partial sums of dW^2 adn_wgrad leaves behind when asked to (``sq=``); 0 = this layer's kernel has no fused form."""
+    d = AdnWgradDesc()
+    d.c_valid = c_valid
+    d.geom, d.ks = (GEMM_S1, ks) if ks else (0, 0)
+    d.dtype, d.B, d.Hs, d.Ws, d.R0, d.R1, d.C0, d.C1 = dtype_code(dtype), B, Hs, Ws, R0, R1, C0, C1
+    d.plain0 = d.gath0 = d.dw = 1
+    d.plain1 = 1 if R1 else None
+    d.gath1 = 1 if C1 else None
+    return int(_lib.load().adn_wgrad_sq_count(C.byref(d)))
+
+
+def wgrad(dtype, B, Hs, Ws, plain0, plain1, gath0, gath1, dw, workspace=None, c_valid=0, ks=0, sq=None):
+    """ks=0: the k4 s2 p1 pair (gathered tensor on the 2x grid); ks in {1,3}: stride-1 ks x ks conv (same grid).
+    sq (optional, f64, wgrad_sq_count(...) elements): receives the partial sums of dW^2 for the fused gradient norm."""
     d = _wgrad_desc(dtype, B, Hs, Ws, plain0, plain1, gath0, gath1, dw, workspace, c_valid, ks)
+    if sq is not None:
+        _dev(sq)
+        if sq.dtype != torch.float64:
+            raise TypeError('wgrad: sq must be float64')
+        d.sq_partials = ptr(sq)
     ev = _prof_begin()
     _lib.call('adn_wgrad', C.byref(d), _stream())
     flops = 2.0 * B * Hs * Ws * (d.R0 + d.R1) * (ks * ks if ks else 16) * (c_valid if c_valid else d.C0 + d.C1)
@@ -428,6 +446,16 @@ def sum_to_scalar(x, out, workspace):
 def grad_norm(grads, max_norm, state, workspace):
     _dev(grads, state, workspace)
     _lib.call('adn_grad_norm', ptr(grads), grads.numel(), max_norm, ptr(state), ptr(workspace),
+              workspace.numel() * workspace.element_size(), _stream())
+
+
+def grad_norm_ranges(grads, ranges, extra, max_norm, state, workspace):
+    """Total gradient norm + clip coefficient from (a) ``ranges`` (int64 [n, 2] rows (offset, length <= 8192), both
+    multiples of 4) of ``grads`` and (b) ``extra``: partial sums of squares the gradient kernels already wrote."""
+    _dev(grads, ranges, extra, state, workspace)
+    nr = 0 if ranges is None else ranges.shape[0]
+    ne = 0 if extra is None else extra.numel()
+    _lib.call('adn_grad_norm_ranges', ptr(grads), ptr(ranges), nr, ptr(extra), ne, max_norm, ptr(state), ptr(workspace),
               workspace.numel() * workspace.element_size(), _stream())
 
 

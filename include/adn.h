@@ -126,9 +126,17 @@ typedef struct {
   int32_t geom;               /* 0: k4 s2 p1 pair (16 taps, gathered tensor on the 2x grid);
                                  ADN_GEMM_S1: ks x ks stride-1 conv (ks*ks taps, same grid), dw [R][ks*ks][c] */
   int32_t ks;
+  double* sq_partials;        /* optional (NULL = off): the kernel that writes the final dw also writes
+                                 adn_wgrad_sq_count(d) partial sums of dw^2 here (one double per workgroup of that
+                                 kernel), the per-layer share of clip_grad_norm_'s total norm (train.py:689) -- saves
+                                 re-reading the gradient.  Summed by adn_grad_norm_ranges.  When the count is 0 (this
+                                 descriptor's kernel path has no fused form) nothing is written and the caller covers dw
+                                 with a range of adn_grad_norm_ranges instead. */
 } AdnWgradDesc;
 int64_t adn_wgrad_workspace_bytes(const AdnWgradDesc* d);
 int adn_wgrad(const AdnWgradDesc* d, void* stream);
+/* Number of doubles adn_wgrad writes to d->sq_partials (0: not fused for this descriptor). */
+int32_t adn_wgrad_sq_count(const AdnWgradDesc* d);
 
 /* Cast/pack master f32 weights ([X][4][4][Y] memory order = torch channels_last of an
  * [X,Y,4,4] parameter) into the two GEMM operand forms.
@@ -478,6 +486,13 @@ int adn_sum_to_scalar(const void* x, int64_t n, int32_t dtype, float* out, void*
 int adn_grad_norm(const float* grads, int64_t n, float max_norm, double* state, void* workspace,
                   int64_t workspace_bytes, void* stream);
 int64_t adn_grad_norm_workspace_bytes(int64_t n);
+/* The same total norm / clip coefficient from two sources: (1) `ranges` = n_ranges rows (offset, length) in elements
+ * into grads (offset % 4 == 0, length <= 8192: one workgroup per row) for the gradients nobody summed yet, and
+ * (2) n_extra partial sums of squares already written by the gradients' producers (AdnWgradDesc.sq_partials).
+ * state[3] = total norm, state[4] = clip coefficient as adn_grad_norm.  workspace: n_ranges doubles. */
+int adn_grad_norm_ranges(const float* grads, const int64_t* ranges, int32_t n_ranges, const double* extra,
+                         int32_t n_extra, float max_norm, double* state, void* workspace, int64_t workspace_bytes,
+                         void* stream);
 /* kind: 0 AdamW (decoupled decay), 1 Adam (L2 in gradient), 2 SGD. Advances state[0..2].
  * bf16_copy (optional, n bf16): mirror of the updated parameters, i.e. next step's S2 GEMM operands. */
 int adn_optimizer_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,

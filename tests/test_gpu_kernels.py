@@ -203,6 +203,56 @@ def test_wgrad(dtype, shape):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('shape', [
+    (32, 128, 0, 128, 1),    # one pixel per image: no pixel split, the MFMA kernel's epilogue writes dW and the partials
+    (32, 64, 64, 128, 2),    # two plain sources, still unsplit
+    (16, 128, 0, 128, 8),    # pixel split -> the slab sum writes dW and the partials
+    (16, 64, 0, 32, 16),     # patch-staged kernel + slab sum
+    (2, 8, 0, 6, 4),         # generic kernel, unsplit: no fused form (count 0), the caller covers dW by a range
+])
+def test_wgrad_norm_partials(dtype, shape):
+    """AdnWgradDesc.sq_partials: the kernel that writes the final dW also leaves partial sums of dW^2 behind
+    (the fused form of clip_grad_norm_'s pass over the gradient, train.py:689).  dW itself must not change (bit-exact
+    against the plain call), the partials must add up to sum(dW^2) of the dW that was written (1e-7 relative: the squares of a
+    16-byte group are f32 products, summed in f64 from there on), and adn_grad_norm_ranges must turn partials + uncovered ranges into the same
+    total norm / clip coefficient as adn_grad_norm over the whole buffer."""
+    B, R0, R1, Cg, Hs = shape
+    R = R0 + R1
+    torch.manual_seed(11)
+    k = K()
+    x = nhwc(torch.randn(B, Cg, 2 * Hs, 2 * Hs), dtype)
+    dz = torch.randn(B, R, Hs, Hs)
+    p0 = nhwc(dz[:, :R0], dtype)
+    p1 = nhwc(dz[:, R0:], dtype) if R1 else None
+    nbytes = k.wgrad_workspace_bytes(dtype, B, Hs, Hs, R0, R1, Cg, 0)
+    ws = torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=DEV)
+    n = R * 16 * Cg
+    pad = 40                                                      # an uncovered "parameter" behind the weight
+    flat = torch.zeros(n + pad, dtype=torch.float32, device=DEV)
+    plain = torch.empty(n, dtype=torch.float32, device=DEV)
+    k.wgrad(dtype, B, Hs, Hs, p0, p1, x, None, plain, ws)
+    cnt = k.wgrad_sq_count(dtype, B, Hs, Hs, R0, R1, Cg, 0)
+    assert (cnt > 0) == (R % 64 == 0)
+    sq = torch.full((max(cnt, 1),), float('nan'), dtype=torch.float64, device=DEV)
+    k.wgrad(dtype, B, Hs, Hs, p0, p1, x, None, flat[:n], ws, sq=sq)
+    assert torch.equal(flat[:n], plain)
+    if cnt == 0:
+        assert bool(torch.isnan(sq).all())                       # documented: nothing is written
+        return
+    want = float((plain.double() ** 2).sum())
+    assert abs(float(sq.sum()) - want) <= 1e-7 * want
+    flat[n:n + 37] = torch.randn(37, device=DEV)
+    state_a = torch.zeros(8, dtype=torch.float64, device=DEV)
+    state_b = torch.zeros(8, dtype=torch.float64, device=DEV)
+    nws = torch.empty(1024 + 8, dtype=torch.float64, device=DEV)
+    k.grad_norm(flat, 0.5, state_a, nws)
+    ranges = torch.tensor([[n, 40]], dtype=torch.int64, device=DEV)
+    k.grad_norm_ranges(flat, ranges, sq, 0.5, state_b, nws)
+    assert abs(float(state_a[3]) - float(state_b[3])) <= 1e-9 * float(state_a[3])      # same f32 group sums, f64 order only
+    assert abs(float(state_a[4]) - float(state_b[4])) <= 1e-9 * float(state_a[4])
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('shape', [(2, 64, 0, 128, 16), (3, 128, 0, 128, 2), (2, 6, 0, 10, 4), (8, 64, 0, 128, 64),
                                    (16, 64, 0, 128, 64)])
 def test_epilogue_z_stats_and_bn(dtype, shape):

@@ -219,6 +219,41 @@ def test_engine_reuses_buffers_and_graph_step_matches_eager():
     assert torch.equal(finals[0], finals[2])        # ... and so is the recorded launch plan
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_fused_gradient_norm_matches_the_pass_over_the_gradient(dtype, monkeypatch):
+    """clip_grad_norm_ (train.py:689): the single-process step takes the total norm from the partial sums the
+    weight-gradient kernels leave behind (+ ranges for BatchNorm / bias / edge-layer parameters) instead of a pass over
+    flat_g.  Same gradients -> the two totals agree to f64 summation order (bound 1e-9 relative); three steps of both
+    variants end in identical parameters."""
+    from audio_depth_estimation_amd import kernels
+    from audio_depth_estimation_amd.engine import FusedTrainer
+    g = torch.Generator().manual_seed(5)
+    audio = torch.rand(4, 2, 128, 128, generator=g).to(DEV)
+    gt = (30 * torch.rand(4, 1, 128, 128, generator=g)).to(DEV)
+    finals, norms = [], []
+    for fused in (True, False):
+        if not fused:
+            monkeypatch.setenv('ADN_NO_FUSED_NORM', '1')
+        torch.manual_seed(0)
+        model = _build('unet_128', 64, False, dtype)
+        model.train()
+        eng = model.engine()
+        tr = FusedTrainer(eng, 'Combined', 0.237, 0.637, 0.869, lr=0.002, clip_norm=1.0)
+        for _ in range(3):
+            tr.step(audio, gt)
+        assert (eng.sq_all is not None) == fused
+        if fused:       # every conv weight but the two thin edge layers is covered by a producer's partials
+            covered = sum(1 for lv in eng.levels for wk in ('down', 'up') if lv.get(wk + '_sq') is not None)
+            assert covered >= 2 * len(eng.levels) - 2
+            st = torch.zeros(8, dtype=torch.float64, device=DEV)
+            kernels.grad_norm(eng.flat_g, 1.0, st, tr.norm_ws)       # the pass over the same gradients
+            assert abs(float(st[3]) - float(tr.state[3])) <= 1e-9 * float(st[3])
+        norms.append(float(tr.state[3]))
+        finals.append(eng.flat_p.detach().clone())
+    assert abs(norms[0] - norms[1]) <= 1e-9 * norms[1]
+    assert torch.equal(finals[0], finals[1])
+
+
 # ---- full-width (ngf 64, MFMA kernels) against numbers generated by the REFERENCE itself ------------------------------
 def _hash_key(key):
     h = 0
