@@ -27,7 +27,7 @@ namespace {
 //                                               zero-record descriptor (every load dropped, zeros in LDS; wrong results)
 //   ADN_IGEMM_SKIP                              timing-only builds: bit 0 / 1 = the operand's LDS-DMA is not issued at all
 struct Tune {
-  int bm = 0, bn = 0, ns = 0, noa = 0, nob = 0, skip = 0, patch = 1, tall = 1, pair = 1;
+  int bm = 0, bn = 0, ns = 0, noa = 0, nob = 0, skip = 0, patch = 1, tall = 1, pair = 1, tinycap = 4;
 };
 const Tune& tune() {
   static Tune t;
@@ -42,6 +42,7 @@ const Tune& tune() {
     if (const char* e = getenv("ADN_IGEMM_PATCH")) t.patch = atoi(e);
     if (const char* e = getenv("ADN_IGEMM_TALL")) t.tall = atoi(e);
     if (const char* e = getenv("ADN_IGEMM_PAIR")) t.pair = atoi(e);
+    if (const char* e = getenv("ADN_IGEMM_TINYCAP")) t.tinycap = atoi(e);
   });
   return t;
 }
@@ -999,7 +1000,14 @@ bool make_plan(const AdnIgemmDesc* d, Plan* pl) {
     // workgroups return: L5 / L6 forward 23.6 / 20.8 -> 20.3 / 16.1 us, D6 dgrad 25.7 -> 19.4 us at a cap of 16
     // (bf16 only: in f32 the cap is neutral for speed, and the f32 reference fixtures of the Base+Residual net hold
     //  gradients through 4 x 4 BatchNorm layers that are sensitive to the summation order at their 5e-3 bound)
-    if (ns > (esz == 2 ? 16 : 64)) ns = esz == 2 ? 16 : 64;
+    // ... unless the layer is so small that more slabs still fit in `tinycap` MB (ADN_IGEMM_TINYCAP, default 4: the
+    // 32-row GEMMs of the innermost level run 64 splits = 2 K-steps per workgroup, 17.8 -> 15.4 us incl. the reduce)
+    int cap = esz == 2 ? 16 : 64;
+    if (esz == 2 && tn.tinycap > 0) {
+      const int64_t by_bytes = ((int64_t)tn.tinycap << 20) / (pl->mout * d->N * 4);
+      if (by_bytes > cap) cap = by_bytes > 64 ? 64 : (int)by_bytes;
+    }
+    if (ns > cap) ns = cap;
     if (ns < 1) ns = 1;
   }
   if (tn.ns >= 1 && ns > tn.ns) ns = tn.ns;                  // tuning knob: cap on the split count
