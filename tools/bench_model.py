@@ -138,7 +138,16 @@ def main():
             acc[1] += meta.get('flops', 0.0)
             acc[2] += 1
             if it == reps - 1 and 'flops' in meta:
-                rows.append((name, ms, meta['flops']))
+                tag = ''
+                try:
+                    d = a[0]._obj
+                    if name == 'adn_igemm':
+                        tag = f'g{d.geom} H{d.Hs} C{d.C0}+{d.C1} N{d.N} epi{d.epi}'
+                    elif name == 'adn_wgrad':
+                        tag = f'H{d.Hs} R{d.R0}+{d.R1} C{d.C0}+{d.C1}'
+                except Exception:
+                    pass
+                rows.append((name + ' ' + tag, ms, meta['flops']))
     total = sum(v[0] for v in fam.values()) / reps
     print(f'{"entry point":34s} {"ms/step":>9s} {"launches":>9s} {"TFLOP/s":>9s}')
     for name, (ms, fl, n) in sorted(fam.items(), key=lambda kv: -kv[1][0]):
@@ -147,7 +156,7 @@ def main():
     print(f'{"sum of kernel events":34s} {total:9.3f}')
     if args.detail:
         for name, ms, fl in rows:
-            print(f'   {name:14s} {ms:8.3f} ms  {fl / 1e9:9.1f} GFLOP  {fl / (ms * 1e-3) / 1e12:7.1f} TF/s')
+            print(f'   {name:44s} {ms:8.3f} ms  {fl / 1e9:9.1f} GFLOP  {fl / (ms * 1e-3) / 1e12:7.1f} TF/s')
     tr._plan, tr._plan_after = None, None
     tr.enable_graph(after_steps=0)
     tr.step(x, gt)
