@@ -416,9 +416,24 @@ void launch_mx8(const MxParams& kp, hipStream_t st) {
   hipLaunchKernelGGL((conv3x3_mx8_kernel<BN, TALL>), dim3(kp.tiles_m * kp.tiles_n), dim3(256), lds, st, kp);
 }
 
-// rows per workgroup: 256 (tall form) for 64-column layers whose images tile by 16 x 16 and still fill the chip
+// Output columns per workgroup (ADN_MX8_BN=128 restores the round-2 rule "128 whenever N % 128 == 0" for an A/B; 64 forces
+// the 64-column forms).  As for the bf16 kernel (igemm.hip make_plan) the tall 256 x 64 tile beats 128 x 128 on the wide
+// layers -- here from 256 output columns on: d3 conv2 92.8 -> 88.5 us (1 747 TFLOP/s), d2 conv2 100.9 -> 99.5; at 128
+// columns it is neutral (forward) to 5 % slower (input gradient), so those keep 128 -- and 64 columns give two workgroups
+// per CU where 128 give one (d4 conv2 32.8 -> 31.5 us).
+int mx8_bn(const AdnMx8ConvDesc* d) {
+  static const int forced = getenv("ADN_MX8_BN") ? atoi(getenv("ADN_MX8_BN")) : 0;
+  if (d->N % 128 != 0) return 64;
+  if (forced == 128) return 128;
+  const int64_t pix = (int64_t)d->B * d->H * d->W;
+  const bool tall_ok = d->N >= 256 && d->H % 16 == 0 && pix / 256 * (d->N / 64) >= 512;
+  const int64_t t128 = pix / 128 * (d->N / 128);
+  if (forced == 64) return 64;
+  return (tall_ok || (t128 >= 256 && t128 < 512)) ? 64 : 128;
+}
+// rows per workgroup: 256 (tall form) for 64-column tiles whose images tile by 16 x 16 and still fill the chip
 int mx8_rows(const AdnMx8ConvDesc* d) {
-  const bool tall = d->N % 128 != 0 && d->H % 16 == 0 && (int64_t)d->B * d->H * d->W / 256 * (d->N / 64) >= 512;
+  const bool tall = mx8_bn(d) == 64 && d->H % 16 == 0 && (int64_t)d->B * d->H * d->W / 256 * (d->N / 64) >= 512;
   return tall ? 256 : 128;
 }
 
@@ -500,7 +515,7 @@ extern "C" int adn_conv3x3_mx8(const AdnMx8ConvDesc* d, void* stream) {
   kp.epi = d->epi;
   kp.seg[0] = d->seg[0];
   kp.seg[1] = d->seg[1];
-  const int bn = d->N % 128 == 0 ? 128 : 64;
+  const int bn = mx8_bn(d);
   const int rows = mx8_rows(d);
   kp.tiles_m = (int)((int64_t)d->B * d->H * d->W / rows);
   kp.tiles_n = d->N / bn;
