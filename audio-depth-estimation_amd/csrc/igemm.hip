@@ -27,7 +27,7 @@ namespace {
 //                                               zero-record descriptor (every load dropped, zeros in LDS; wrong results)
 //   ADN_IGEMM_SKIP                              timing-only builds: bit 0 / 1 = the operand's LDS-DMA is not issued at all
 struct Tune {
-  int bm = 0, bn = 0, ns = 0, noa = 0, nob = 0, skip = 0, patch = 1, tall = 1, pair = 1, tinycap = 4;
+  int bm = 0, bn = 0, ns = 0, noa = 0, nob = 0, skip = 0, patch = 1, tall = 1, pair = 1, tinycap = 4, bn_t2 = 0;
 };
 const Tune& tune() {
   static Tune t;
@@ -43,6 +43,7 @@ const Tune& tune() {
     if (const char* e = getenv("ADN_IGEMM_TALL")) t.tall = atoi(e);
     if (const char* e = getenv("ADN_IGEMM_PAIR")) t.pair = atoi(e);
     if (const char* e = getenv("ADN_IGEMM_TINYCAP")) t.tinycap = atoi(e);
+    if (const char* e = getenv("ADN_IGEMM_BN_T2")) t.bn_t2 = atoi(e);
   });
   return t;
 }
@@ -986,6 +987,11 @@ bool make_plan(const AdnIgemmDesc* d, Plan* pl) {
   const Tune& tn = tune();
   if (tn.bm) pl->bm = tn.bm == 256 ? 256 : 128;
   if (tn.bn) pl->bn = (tn.bn == 128 && d->N % 128 == 0) ? 128 : 64;
+  // Transposed-conv geometry (forward of the up path, input gradients of the down path): 64-column tiles throughout --
+  // the tall 256 x 64 patch form on the 16 x 16 ... 64 x 64 image levels (less patch halo per pixel, half the weight bytes
+  // per K-step), twice the workgroups on the split-K levels.  Headline step 2.909 -> 2.860 ms and 2.932 -> 2.894 ms on two
+  // boxes (ADN_IGEMM_BN_T2=128 restores 128-column tiles for an A/B; the two-image PAIR form keeps its 128 columns).
+  if (d->geom == ADN_GEMM_T2 && d->dtype == ADN_BF16 && !tn.bn) pl->bn = (tn.bn_t2 == 128 && d->N % 128 == 0) ? 128 : 64;
   // exactly one 128 x 128 workgroup per CU (L3 forward of unet_256: 64 x 4 tiles) leaves every CU a single K loop with
   // nothing to overlap its LDS-DMA round trips; 64-column tiles give each CU two: 52.2 -> 47.9 us (S2 only: measured there)
   if (d->geom == ADN_GEMM_S2 && d->dtype == ADN_BF16 && pl->bn == 128 && !tn.bn) {
