@@ -14,6 +14,17 @@ inline unsigned blocks_for(int64_t n, int per_block = 256) {
   return (unsigned)b;
 }
 
+// BatchNorm apply kernels (bn_act / bn_bwd_apply): 1024 workgroups -- a thread keeps its 8 channels' coefficients in
+// registers over >= 4x more 16-byte chunks than at 4096 (bn_bwd_apply of the headline step 133 -> 115 us, of RGBDepthNet
+// 1.48 -> 1.02 ms together with the hoisted coefficient loads; 8192: 134 / 1.08, 2048: 122 / 1.02).  ADN_BN_BLOCKS overrides.
+inline unsigned bn_blocks_for(int64_t n) {
+  static const int cap = getenv("ADN_BN_BLOCKS") ? atoi(getenv("ADN_BN_BLOCKS")) : 1024;
+  int64_t b = adn_cdiv(n, 256);
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
 // master [X][4][4][Y] f32 -> s2 [X][16][Ypad] (cast, zero padded channels): coalesced both sides
 template <typename T>
 __global__ __launch_bounds__(256) void pack_s2_kernel(const float* master, int X, int Y, int Ypad, T* s2) {
@@ -277,15 +288,30 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* z, int64_t pixels,
     const unsigned cpg = (unsigned)C >> 3;
     const unsigned step = (unsigned)(((int64_t)gridDim.x * 256) % cpg);
     unsigned cgp = (unsigned)(((int64_t)blockIdx.x * 256 + threadIdx.x) % cpg);
+    // The grid stride is a multiple of the channel-group count whenever C is a power of two (every layer of the five
+    // nets): the thread then stays on the SAME 8 channels and their coefficients are loaded once, not per 16-byte chunk
+    // (the per-chunk loads were 2/3 of the kernel's L1 traffic)
+    float sc[8], sh[8];
+    auto load_coef = [&](int c) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        sc[k] = scale[c + k];
+        sh[k] = shift[c + k];
+      }
+    };
+    const bool fixed = step == 0;
+    if (fixed) load_coef((int)(cgp << 3));
     for (int64_t gidx = (int64_t)blockIdx.x * 256 + threadIdx.x; gidx < groups; gidx += (int64_t)gridDim.x * 256) {
       const int64_t e = gidx << 3;
-      const int c = (int)(cgp << 3);
-      cgp += step;
-      if (cgp >= cpg) cgp -= cpg;
+      if (!fixed) {
+        load_coef((int)(cgp << 3));
+        cgp += step;
+        if (cgp >= cpg) cgp -= cpg;
+      }
       float v[8], o[8];
       load8<T>(z, e, v);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = v[k] * scale[c + k] + shift[c + k];
+      for (int k = 0; k < 8; ++k) v[k] = v[k] * sc[k] + sh[k];
       if (out_leaky) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) o[k] = v[k] > 0.f ? v[k] : v[k] * slope;
@@ -339,18 +365,34 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(T* g, const T* z, int
     const unsigned cpg = (unsigned)C >> 3;
     const unsigned step = (unsigned)(((int64_t)gridDim.x * 256) % cpg);
     unsigned cgp = (unsigned)(((int64_t)blockIdx.x * 256 + threadIdx.x) % cpg);
+    // (coefficients of the thread's 8 channels loaded once when the grid stride keeps it on them: see bn_act_kernel)
+    float cm[8], ci[8], cs[8], c0[8], c1[8];
+    auto load_coef = [&](int c) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        cm[k] = mean[c + k];
+        ci[k] = istd[c + k];
+        cs[k] = scale[c + k];
+        c0[k] = coef[c + k];
+        c1[k] = coef[C + c + k];
+      }
+    };
+    const bool fixed = step == 0;
+    if (fixed) load_coef((int)(cgp << 3));
     for (int64_t gidx = (int64_t)blockIdx.x * 256 + threadIdx.x; gidx < groups; gidx += (int64_t)gridDim.x * 256) {
       const int64_t e = gidx << 3;
-      const int c = (int)(cgp << 3);
-      cgp += step;
-      if (cgp >= cpg) cgp -= cpg;
+      if (!fixed) {
+        load_coef((int)(cgp << 3));
+        cgp += step;
+        if (cgp >= cpg) cgp -= cpg;
+      }
       float gv[8], zv[8];
       load8<T>(g, e, gv);
       load8<T>(z, e, zv);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const float xh = (zv[k] - mean[c + k]) * istd[c + k];
-        gv[k] = scale[c + k] * (gv[k] - coef[c + k] - xh * coef[C + c + k]);
+        const float xh = (zv[k] - cm[k]) * ci[k];
+        gv[k] = cs[k] * (gv[k] - c0[k] - xh * c1[k]);
       }
       store8<T>(g, e, gv);
       if constexpr (sizeof(T) == 2) {
@@ -628,11 +670,11 @@ extern "C" int adn_bn_act(const void* z, int64_t pixels, int32_t C, int32_t dtyp
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int64_t work = (C & 7) == 0 ? pixels * C / 8 : pixels * C;
   if (dtype == ADN_BF16)
-    hipLaunchKernelGGL((bn_act_kernel<uint16_t>), dim3(blocks_for(work)), dim3(256), 0, st,
+    hipLaunchKernelGGL((bn_act_kernel<uint16_t>), dim3(bn_blocks_for(work)), dim3(256), 0, st,
                        reinterpret_cast<const uint16_t*>(z), pixels, C, scale, shift, slope,
                        reinterpret_cast<uint16_t*>(out_leaky), reinterpret_cast<uint16_t*>(out_relu));
   else
-    hipLaunchKernelGGL((bn_act_kernel<float>), dim3(blocks_for(work)), dim3(256), 0, st,
+    hipLaunchKernelGGL((bn_act_kernel<float>), dim3(bn_blocks_for(work)), dim3(256), 0, st,
                        reinterpret_cast<const float*>(z), pixels, C, scale, shift, slope,
                        reinterpret_cast<float*>(out_leaky), reinterpret_cast<float*>(out_relu));
   ADN_CHECK_LAUNCH();
@@ -644,7 +686,7 @@ extern "C" int adn_bn_act_mx8(const void* z, int64_t pixels, int32_t C, const fl
                               void* out_relu, void* out8, void* out_scales, void* stream) {
   ADN_CHECK_ARG(z && pixels > 0 && C > 0 && C % 32 == 0 && scale && shift && out_relu && out8 && out_scales,
                 "adn_bn_act_mx8: bad arguments (C=%d must be a multiple of 32)", C);
-  hipLaunchKernelGGL((bn_act_kernel<uint16_t>), dim3(blocks_for(pixels * C / 8)), dim3(256), 0,
+  hipLaunchKernelGGL((bn_act_kernel<uint16_t>), dim3(bn_blocks_for(pixels * C / 8)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const uint16_t*>(z), pixels, C, scale, shift, 0.f,
                      (uint16_t*)nullptr, reinterpret_cast<uint16_t*>(out_relu), reinterpret_cast<uint2*>(out8),
                      reinterpret_cast<uint8_t*>(out_scales));
@@ -656,7 +698,7 @@ extern "C" int adn_bn_bwd_apply_mx8(void* g, const void* z, int64_t pixels, int3
                                     const float* istd, const float* coef, void* out8, void* out_scales, void* stream) {
   ADN_CHECK_ARG(g && z && pixels > 0 && C > 0 && C % 32 == 0 && scale && mean && istd && coef && out8 && out_scales,
                 "adn_bn_bwd_apply_mx8: bad arguments (C=%d must be a multiple of 32)", C);
-  hipLaunchKernelGGL((bn_bwd_apply_kernel<uint16_t>), dim3(blocks_for(pixels * C / 8)), dim3(256), 0,
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<uint16_t>), dim3(bn_blocks_for(pixels * C / 8)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), reinterpret_cast<uint16_t*>(g),
                      reinterpret_cast<const uint16_t*>(z), pixels, C, scale, mean, istd, coef,
                      reinterpret_cast<uint2*>(out8), reinterpret_cast<uint8_t*>(out_scales));
@@ -728,11 +770,11 @@ extern "C" int adn_bn_bwd_apply(void* g, const void* z, int64_t pixels, int32_t 
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int64_t work = (C & 7) == 0 ? pixels * C / 8 : pixels * C;
   if (dtype == ADN_BF16)
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<uint16_t>), dim3(blocks_for(work)), dim3(256), 0, st,
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<uint16_t>), dim3(bn_blocks_for(work)), dim3(256), 0, st,
                        reinterpret_cast<uint16_t*>(g), reinterpret_cast<const uint16_t*>(z), pixels, C, scale, mean,
                        istd, coef);
   else
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(blocks_for(work)), dim3(256), 0, st,
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(bn_blocks_for(work)), dim3(256), 0, st,
                        reinterpret_cast<float*>(g), reinterpret_cast<const float*>(z), pixels, C, scale, mean, istd,
                        coef);
   ADN_CHECK_LAUNCH();

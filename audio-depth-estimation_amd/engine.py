@@ -311,7 +311,7 @@ class UNetEngine(FlatParamEngine):
 
     # tensors up to this many elements take the one-launch finalize + apply kernels (innermost levels: the two
     # separate launches cost 6-9 us each there, launch-latency bound)
-    BN_FUSED_MAX = 1 << 20
+    BN_FUSED_MAX = int(os.environ.get('ADN_BN_FUSED_MAX', 1 << 20))
 
     def _bn_forward(self, lv, tag, bn, count, P, z, slope, out_leaky, out_relu):
         """Train-mode BatchNorm + activation of a raw conv output: statistics finalize (+ running stats) and apply."""
