@@ -27,7 +27,7 @@ namespace {
 //                                               zero-record descriptor (every load dropped, zeros in LDS; wrong results)
 //   ADN_IGEMM_SKIP                              timing-only builds: bit 0 / 1 = the operand's LDS-DMA is not issued at all
 struct Tune {
-  int bm = 0, bn = 0, ns = 0, noa = 0, nob = 0, skip = 0, patch = 1, tall = 1, pair = 1, tinycap = 4, bn_t2 = 0;
+  int bm = 0, bn = 0, ns = 0, noa = 0, nob = 0, skip = 0, patch = 1, tall = 1, pair = 1, tinycap = 4, bn_t2 = 0, onepx = 1;
 };
 const Tune& tune() {
   static Tune t;
@@ -43,6 +43,7 @@ const Tune& tune() {
     if (const char* e = getenv("ADN_IGEMM_TALL")) t.tall = atoi(e);
     if (const char* e = getenv("ADN_IGEMM_PAIR")) t.pair = atoi(e);
     if (const char* e = getenv("ADN_IGEMM_TINYCAP")) t.tinycap = atoi(e);
+    if (const char* e = getenv("ADN_IGEMM_ONEPX")) t.onepx = atoi(e);
     if (const char* e = getenv("ADN_IGEMM_BN_T2")) t.bn_t2 = atoi(e);
   });
   return t;
@@ -65,6 +66,7 @@ struct KParams {
   float* slab;    // split-K / generic scratch
   unsigned rec_a, rec_b;   // buffer-descriptor record bytes of the gathered / weight operands (0 = timing-only build)
   int skip;                // timing-only builds: bit 0 / 1 = do not even ISSUE the gathered / weight operand's LDS-DMA
+  int onepx;               // 1 x 1 small-grid images (the innermost U-Net level): only the taps that can be in range are walked
   int lgW, lgH;            // log2 of Ws / Hs when both are powers of two (every U-Net level), else -1: the pixel decode
                            // of the tile prologue / epilogue then uses shifts instead of ~40-instruction integer divisions
 };
@@ -228,12 +230,23 @@ __global__ __launch_bounds__(BM * NWN, 2) void igemm_mfma_kernel(KParams p) {
   // One K-step of LDS-DMA = APASS + BPASS wave-instructions, issued right behind the step's barrier.  (Measured and
   // rejected in round 2: spreading the pieces between the MFMA rows of the step with sched_barrier fences -- L3 forward
   // 55 -> 67 us, D4 forward 60 -> 80 us, the others within 3 %.)
+  // 1 x 1 images: of the 16 (S2) / 4 (T2 phase) taps only 4 / 1 can ever be in range (the 2 x 2 input under the single
+  // output pixel, resp. the one input pixel of the phase); the K loop walks those, the host counts the K-steps the same way
+  const bool onepx = p.onepx != 0;
+  auto real_tap = [&](int v) -> int {
+    if (!onepx) return v;
+    if constexpr (GEOM == ADN_GEMM_S2) return 5 + (v & 1) + 4 * (v >> 1);       // (ky, kx) in {1, 2} x {1, 2}
+    else if constexpr (GEOM == ADN_GEMM_T2) return phase;                        // ty = ph, tx = pw
+    else return v;
+  };
   auto issue_step = [&](int s, int buf) {
     char* adst = smem + buf * STAGE_BYTES + wave * 1024;
     char* bdst = adst + BM * 128;
+    int kelem = s * BK;                        // first weight-row element of the step
     if constexpr (WIDE) {
       // whole K-step inside one tap and one source: everything but the validity bit is scalar
-      const int tap = is_tap, c0 = is_c0;
+      const int tap = real_tap(is_tap), c0 = is_c0;
+      kelem = tap * Cin + c0;
       const bool second = c0 >= p.C0;
       const int Cs = second ? p.C1 : p.C0;
       const int coff = second ? c0 - p.C0 : c0;
@@ -274,7 +287,7 @@ __global__ __launch_bounds__(BM * NWN, 2) void igemm_mfma_kernel(KParams p) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lptr_t)(adst + j * (RPASS * 128)), 16, voff, 0, 0, 0);
       }
     }
-    const int soffb = s * 128;
+    const int soffb = kelem * ESZ;
     if (!(p.skip & 2))
 #pragma unroll
     for (int j = 0; j < BPASS; ++j)
@@ -944,6 +957,7 @@ struct Plan {
   int nsplit;
   int tiles_m, tiles_n, phases;
   int kpt, ksteps;
+  bool onepx;
   int64_t mout;
   int64_t partial_rows;
   int64_t slab_bytes;
@@ -968,6 +982,7 @@ bool make_plan(const AdnIgemmDesc* d, Plan* pl) {
                        (d->seg[1].channels % 64 == 0);
   pl->mfma = aligned;
   pl->patch = pl->tall = pl->pair = false;
+  pl->onepx = false;
   if (!aligned) {
     pl->bn = 0;
     pl->nsplit = 1;
@@ -1013,6 +1028,9 @@ bool make_plan(const AdnIgemmDesc* d, Plan* pl) {
   pl->tiles_n = d->N / pl->bn;
   pl->kpt = 0;
   pl->ksteps = pl->wstride / bk;
+  // innermost U-Net level (1 x 1 small-grid images): 12 of 16 (S2) / 3 of 4 (T2) taps are padding for EVERY row
+  pl->onepx = d->dtype == ADN_BF16 && pl->wide && d->Hs == 1 && d->Ws == 1 && d->geom != ADN_GEMM_S1 && tn.onepx != 0;
+  if (pl->onepx) pl->ksteps = (d->geom == ADN_GEMM_S2 ? 4 : 1) * (Cin / bk);
   const int64_t tiles = (int64_t)pl->tiles_m * pl->tiles_n * pl->phases;
   int ns = 1;
   if (tiles < 256) {
@@ -1144,6 +1162,7 @@ int run(const AdnIgemmDesc* d, const Plan& pl, hipStream_t st) {
   kp.Msmall = d->B * d->Hs * d->Ws;
   kp.kpt = pl.kpt;
   kp.ksteps = pl.ksteps;
+  kp.onepx = pl.onepx ? 1 : 0;
   kp.nsplit = pl.nsplit;
   kp.tiles_m = pl.tiles_m;
   kp.tiles_n = pl.tiles_n;

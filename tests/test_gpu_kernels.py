@@ -71,6 +71,8 @@ SHAPES = [
     (8, 64, 64, 64, 64),     # T2: 128 tiles of 16 x 16 pixels x 4 phases -> the tall 4 x 1-wave patch kernel (BN = 64)
     (4, 128, 0, 256, 8),     # 8 x 8 small-grid images: two images per patch tile (PAIR form), S2 and T2
     (6, 64, 64, 128, 8),     # PAIR form with two gathered sources, three image pairs
+    (32, 128, 0, 128, 1),    # 1 x 1 small-grid images (innermost level): only the 4 (S2) / 1 (T2 phase) in-range taps are walked
+    (8, 64, 64, 128, 1),     # same with two gathered sources
     (2, 6, 0, 10, 4),        # generic direct path
     (1, 3, 5, 1, 5),         # generic, two sources, single output channel, odd size
 ]
