@@ -48,6 +48,9 @@ def test_argument_validation_without_gpu():
     assert lib.adn_wgrad(ctypes.byref(w), None) == -1
     assert lib.adn_frontend_workspace_bytes(0, 0, 0) == -1
     assert lib.adn_frontend_workspace_bytes(2, 7782, 0) > 0
+    assert lib.adn_wgrad_sq_count(ctypes.byref(w)) == 0                      # invalid descriptor: "not fused", nothing written
+    assert lib.adn_grad_norm_ranges(None, None, 0, None, 0, 1.0, None, None, 0, None) == -1
+    assert b'adn_grad_norm_ranges' in lib.adn_last_error()
 
 
 def test_plan_queries_cover_unet256_shapes():
@@ -61,6 +64,16 @@ def test_plan_queries_cover_unet256_shapes():
     P, ws = K.igemm_query(torch.bfloat16, 0, 32, 128, 128, 2, 0, 64, [64])         # L0: generic path slab
     assert ws == 32 * 128 * 128 * 64 * 4
     assert K.wgrad_workspace_bytes(torch.bfloat16, 32, 64, 64, 128, 0, 64, 0) > 0
+    # plan rules of round 2 (host only): the transposed-conv geometry runs 64-column tiles -> D2 forward (B 32, 32 x 32 small
+    # grid, 128 output columns) in the tall 256-row form: 32768 / 256 row tiles x 4 phases partial rows
+    P, ws = K.igemm_query(torch.bfloat16, 1, 32, 32, 32, 256, 256, 128, [128])
+    assert P == 32768 // 256 * 4 and ws == 0
+    # 1 x 1 small-grid images: 4 of 16 taps are walked -> 4 * 512 / 64 = 32 K-steps, 16 splits of the four 32-row column tiles
+    P, ws = K.igemm_query(torch.bfloat16, 0, 32, 1, 1, 512, 0, 512, [512])
+    assert ws == 16 * 32 * 512 * 4
+    # fused gradient norm: one partial per slab-sum workgroup (L1 weight gradient), none for the generic kernel
+    assert K.wgrad_sq_count(torch.bfloat16, 32, 64, 64, 128, 0, 64, 0) > 0
+    assert K.wgrad_sq_count(torch.bfloat16, 2, 4, 4, 8, 0, 6, 0) == 0
 
 
 def test_product_path_has_no_oracle_import():
