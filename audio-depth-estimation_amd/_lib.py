@@ -183,6 +183,9 @@ _PROTOS = {
     'adn_loss_workspace_bytes': (c_int64, [c_int64]),
     'adn_loss_finish': (C.c_int, [c_void_p, c_void_p, c_int64, c_float, c_int32, c_float, c_void_p, c_int32,
                                   c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    'adn_loss_finish_dz': (C.c_int, [c_void_p, c_void_p, c_int64, c_float, c_int32, c_float, c_void_p, c_int32,
+                                     c_float, c_float, c_float, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int64,
+                                     c_void_p]),
     'adn_final_act_bwd': (C.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     'adn_convt_n1_workspace_bytes': (c_int64, [c_int32, c_int32, c_int32]),
     'adn_convt_n1_forward': (C.c_int, [c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32,

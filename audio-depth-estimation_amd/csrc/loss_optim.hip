@@ -66,10 +66,14 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const double* partial
   }
 }
 
+// final_act >= 0 (0 ReLU, 1 Sigmoid; pred is the activation's OUTPUT): grad receives d loss / d pre-activation
+// = d loss / d pred * act'(pred) -- what adn_final_act_bwd would make of it -- and bias_partials[block] its partial sum
+// (the gradient of the last layer's bias: sum over all pixels), so neither needs a pass of its own.
 __global__ __launch_bounds__(256) void loss_finish_kernel(const float* pred, const float* gt, int64_t n, float scale,
                                                           int mask_mode, float eps, const double* stats,
                                                           int criterion, float l1w, float sw, float lam,
-                                                          float* loss_out, float* grad) {
+                                                          float* loss_out, float* grad, int final_act = -1,
+                                                          double* bias_partials = nullptr) {
   const double N = stats[0];
   double w1 = criterion == 0 ? 1.0 : (criterion == 1 ? 0.0 : (double)l1w);
   double w2 = criterion == 0 ? 0.0 : (criterion == 1 ? 1.0 : (double)sw);
@@ -101,11 +105,13 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const float* pred, con
   const float c1 = N > 0.0 ? (float)(w1 * (double)scale / N) : 0.f;
   const float c2 = (N > 0.0 && silog > 0.0) ? (float)(w2 * (double)scale / (N * silog)) : 0.f;
   const float lm = (float)((double)lam * mean_d);
+  double bsum = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float g0 = gt[i];
+    const float o = pred[i];
     float gr = 0.f;
     if (valid_px(g0, mask_mode)) {
-      const float p = pred[i] * scale, g = g0 * scale;
+      const float p = o * scale, g = g0 * scale;
       const float diff = p - g;
       gr = c1 * (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f));
       if (c2 != 0.f && p >= eps) {
@@ -113,7 +119,16 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const float* pred, con
         gr += c2 * (d - lm) / p;
       }
     }
+    if (final_act >= 0) {
+      gr *= final_act == 1 ? o * (1.0f - o) : (o > 0.f ? 1.0f : 0.0f);      // as final_act_bwd_kernel
+      bsum += (double)gr;
+    }
     grad[i] = gr;
+  }
+  if (bias_partials) {         // uniform
+    __shared__ double bsh[4];
+    bsum = block_sum_d(bsum, bsh);
+    if (threadIdx.x == 0) bias_partials[blockIdx.x] = bsum;
   }
 }
 
@@ -324,6 +339,30 @@ extern "C" int adn_loss_finish(const float* pred, const float* gt, int64_t n, fl
                      gt, n, scale, mask_mode, eps, stats, criterion, l1_weight, silog_weight, silog_lambda, loss_out,
                      grad);
   ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}
+
+extern "C" int adn_loss_finish_dz(const float* pred, const float* gt, int64_t n, float scale, int32_t mask_mode,
+                                  float eps, const double* stats, int32_t criterion, float l1_weight, float silog_weight,
+                                  float silog_lambda, float* loss_out, float* dz, int32_t final_act, float* bias_grad,
+                                  void* workspace, int64_t workspace_bytes, void* stream) {
+  ADN_CHECK_ARG(pred && gt && n > 0 && stats && dz && workspace, "adn_loss_finish_dz: bad arguments");
+  ADN_CHECK_ARG(criterion >= 0 && criterion <= 2, "adn_loss_finish_dz: criterion %d (0 L1, 1 SIlog, 2 Combined)", criterion);
+  ADN_CHECK_ARG(mask_mode >= 0 && mask_mode <= 2, "adn_loss_finish_dz: bad mask_mode %d", mask_mode);
+  ADN_CHECK_ARG(final_act == 0 || final_act == 1, "adn_loss_finish_dz: final_act %d (0 ReLU, 1 Sigmoid)", final_act);
+  int64_t nb = adn_cdiv(n, 256);
+  if (nb > 4096) nb = 4096;
+  ADN_CHECK_ARG(workspace_bytes >= nb * 8, "adn_loss_finish_dz: workspace too small");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  double* part = reinterpret_cast<double*>(workspace);
+  hipLaunchKernelGGL(loss_finish_kernel, dim3((unsigned)nb), dim3(256), 0, st, pred, gt, n, scale, mask_mode, eps, stats,
+                     criterion, l1_weight, silog_weight, silog_lambda, loss_out, dz, final_act,
+                     bias_grad ? part : nullptr);
+  ADN_CHECK_LAUNCH();
+  if (bias_grad) {
+    hipLaunchKernelGGL(sum_final_f32_kernel, dim3(1), dim3(256), 0, st, part, (int)nb, bias_grad);
+    ADN_CHECK_LAUNCH();
+  }
   return ADN_OK;
 }
 

@@ -345,19 +345,31 @@ class UNetEngine(FlatParamEngine):
             off = self.offset[id(param)]
             _lib.record_py(lambda: self.on_grad_ready(off))
 
-    def backward(self, gout, fused_norm=False):
+    def dz_target(self):
+        """Where a loss kernel may write d loss / d pre-activation of the output directly (adn_loss_finish_dz), together
+        with the bias-gradient slot of the last layer: (dz [B, 1, H, W] f32, bias_grad or None, final_act), or None when
+        this engine's last layer wants the padded bf16 form (then ``backward`` converts ``gout`` itself)."""
+        l0 = self.levels[0]
+        if not getattr(self, 'edge_path', False) or l0.get('cu_out') != 1 or os.environ.get('ADN_NO_FUSED_DZ'):
+            return None
+        bias = l0['up'].bias
+        return l0['dz0'], (None if bias is None else self._flat_slice(self.flat_g, bias)), 1 if self.depth_norm else 0
+
+    def backward(self, gout, fused_norm=False, dz_ready=False):
         """gout: d loss / d output, f32 [B, Cout, H, W].  Fills flat_g (all parameters); with ``fused_norm`` also
-        ``sq_all`` (see _prepare_fused_norm)."""
+        ``sq_all`` (see _prepare_fused_norm).  ``dz_ready``: the caller's loss kernel already wrote ``dz_target()``
+        (gout is ignored)."""
         T, B, n, L, ws = self.dtype, self.B, self.n, self.levels, self.workspace
         fused_norm = fused_norm and self.sq_all is not None
         l0 = L[0]
         if l0['cu_out'] != 1:
             raise NotImplementedError('backward is implemented for output_nc == 1 (the depth map)')
-        gout = gout.contiguous().float()
-        K.final_act_bwd(gout, l0['out'], 1 if self.depth_norm else 0, l0['dz0'])
         up0 = l0['up']
-        if up0.bias is not None:
-            K.sum_to_scalar(l0['dz0'], self._flat_slice(self.flat_g, up0.bias), self.red_ws)
+        if not dz_ready:
+            gout = gout.contiguous().float()
+            K.final_act_bwd(gout, l0['out'], 1 if self.depth_norm else 0, l0['dz0'])
+            if up0.bias is not None:
+                K.sum_to_scalar(l0['dz0'], self._flat_slice(self.flat_g, up0.bias), self.red_ws)
         # ---- up layers, outermost first
         for i in range(n):
             lv = L[i]
@@ -625,6 +637,7 @@ class FusedTrainer:
             self._setup(audio.device)
         pred = eng.forward(audio, True)
         gt = gt.contiguous().float()
+        dz_ready = False
         if self.gout is None or self.gout.shape != pred.shape:
             self.gout = torch.empty_like(pred)
         if self.criterion == 3:       # DepthLoss: unmasked L1 + total variation (train_rgb_depth.py:43-87)
@@ -637,15 +650,25 @@ class FusedTrainer:
             K.loss_stats(pred, gt, self.scale, self.mask_mode, 1e-6, self.stats, self.loss_ws)
             if self.ddp is not None:      # one global-batch loss, as under DataParallel
                 _lib.record_py(lambda: self.ddp.all_reduce_loss_stats(self.stats))
-            K.loss_finish(pred, gt, self.scale, self.mask_mode, 1e-6, self.stats, self.criterion, self.l1_weight,
-                          self.silog_weight, self.silog_lambda, self.loss, self.gout)
+            # U-Net with the thin last layer: the loss kernel writes d loss / d pre-activation and the bias gradient itself
+            target = eng.dz_target() if (hasattr(eng, 'dz_target') and self.criterion <= 2) else None
+            if target is not None:
+                dz, bias_grad, final_act = target
+                K.loss_finish_dz(pred, gt, self.scale, self.mask_mode, 1e-6, self.stats, self.criterion, self.l1_weight,
+                                 self.silog_weight, self.silog_lambda, self.loss, dz, final_act, bias_grad, self.loss_ws)
+                dz_ready = True
+            else:
+                K.loss_finish(pred, gt, self.scale, self.mask_mode, 1e-6, self.stats, self.criterion, self.l1_weight,
+                              self.silog_weight, self.silog_lambda, self.loss, self.gout)
         if self.ddp is not None:
             _lib.record_py(self.ddp.begin_backward)
         # single process: the weight-gradient kernels leave their share of the total norm behind (no pass over flat_g);
         # under the reducer the norm is that of the all-reduced gradients, taken afterwards
         fused = (self.clip_norm is not None and self.ddp is None and getattr(eng, 'supports_fused_norm', False)
                  and eng.sq_all is not None)
-        if fused:
+        if dz_ready:
+            eng.backward(self.gout, fused_norm=fused, dz_ready=True)
+        elif fused:
             eng.backward(self.gout, fused_norm=True)
         else:
             eng.backward(self.gout)

@@ -378,6 +378,15 @@ def loss_finish(pred, gt, scale, mask_mode, eps, stats, criterion, l1_weight, si
               l1_weight, silog_weight, silog_lambda, ptr(loss_out), ptr(grad), _stream())
 
 
+def loss_finish_dz(pred, gt, scale, mask_mode, eps, stats, criterion, l1_weight, silog_weight, silog_lambda, loss_out, dz,
+                   final_act, bias_grad, workspace):
+    """loss_finish + final_act_bwd + the last layer's bias gradient in one pass (1-channel prediction = activation output)."""
+    _dev(pred, gt, stats, loss_out, dz, bias_grad, workspace)
+    _lib.call('adn_loss_finish_dz', ptr(pred), ptr(gt), pred.numel(), scale, mask_mode, eps, ptr(stats), criterion,
+              l1_weight, silog_weight, silog_lambda, ptr(loss_out), ptr(dz), final_act, ptr(bias_grad), ptr(workspace),
+              workspace.numel() * workspace.element_size(), _stream())
+
+
 def final_act_bwd(gout, out, final_act, dz):
     """dz [pixels, Cpad]: channel 0 = gout * act'(out), padded channels zero."""
     _dev(gout, out, dz)

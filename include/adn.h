@@ -439,6 +439,14 @@ int adn_loss_finish(const float* pred, const float* gt, int64_t n, float scale, 
                     float eps, const double* stats, int32_t criterion, float l1_weight,
                     float silog_weight, float silog_lambda, float* loss_out, float* grad,
                     void* stream);
+/* adn_loss_finish for a 1-channel prediction that is the OUTPUT of the generator's last activation (final_act 0 ReLU,
+ * 1 Sigmoid; train.py:656-674 through unetbaseline_model.py:201-206): dz (f32, n) = d loss / d pred * act'(pred), i.e. what
+ * adn_final_act_bwd makes of adn_loss_finish's grad, and bias_grad (optional, f32 scalar) = sum(dz), the gradient of the last
+ * layer's bias -- both without a pass of their own.  criterion 0-2.  workspace: min(4096, ceil(n / 256)) doubles. */
+int adn_loss_finish_dz(const float* pred, const float* gt, int64_t n, float scale, int32_t mask_mode, float eps,
+                       const double* stats, int32_t criterion, float l1_weight, float silog_weight, float silog_lambda,
+                       float* loss_out, float* dz, int32_t final_act, float* bias_grad, void* workspace,
+                       int64_t workspace_bytes, void* stream);
 /* Derivative of the generator's last activation (ReLU or Sigmoid, unetbaseline_model.py:201-206):
  * dz (dtype, [pixels][c_pad], channel 0 = gout * act'(out), other channels zero). */
 int adn_final_act_bwd(const float* gout, const float* out, int64_t n, int32_t final_act,

@@ -254,6 +254,56 @@ def test_fused_gradient_norm_matches_the_pass_over_the_gradient(dtype, monkeypat
     assert torch.equal(finals[0], finals[1])
 
 
+@pytest.mark.parametrize('depth_norm', [False, True])
+def test_loss_kernel_writes_dz_and_bias_gradient(depth_norm, monkeypatch):
+    """adn_loss_finish_dz: the loss kernel writes d loss / d pre-activation of the 1-channel output (ReLU or Sigmoid
+    derivative applied) and the last layer's bias gradient itself.  Kernel level: dz is bit-identical to adn_loss_finish
+    followed by adn_final_act_bwd, the bias gradient equals sum(dz) (1e-6 relative: f64 partial sums, cast to f32).  Step
+    level: three fused steps end in the same parameters as with ADN_NO_FUSED_DZ=1."""
+    from audio_depth_estimation_amd import kernels
+    from audio_depth_estimation_amd.engine import FusedTrainer
+    g = torch.Generator().manual_seed(9)
+    pred = torch.rand(4, 1, 64, 64, generator=g)
+    pred[pred < 0.2] = 0.0                                   # ReLU outputs hold exact zeros
+    if not depth_norm:
+        pred = pred * 20.0
+    gt = 30 * torch.rand(4, 1, 64, 64, generator=g)
+    gt[gt < 3] = 0
+    pred, gt = pred.to(DEV), gt.to(DEV)
+    scale = 30.0 if depth_norm else 1.0
+    fa = 1 if depth_norm else 0
+    stats = torch.zeros(4, dtype=torch.float64, device=DEV)
+    ws = torch.empty(4096 + 8, dtype=torch.float64, device=DEV)
+    kernels.loss_stats(pred, gt, scale, 0, 1e-6, stats, ws)
+    loss_a, loss_b = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+    grad, dz_ref, dz = torch.empty_like(pred), torch.empty_like(pred), torch.empty_like(pred)
+    kernels.loss_finish(pred, gt, scale, 0, 1e-6, stats, 2, 0.237, 0.637, 0.869, loss_a, grad)
+    kernels.final_act_bwd(grad, pred, fa, dz_ref)
+    bias = torch.zeros(1, device=DEV)
+    kernels.loss_finish_dz(pred, gt, scale, 0, 1e-6, stats, 2, 0.237, 0.637, 0.869, loss_b, dz, fa, bias, ws)
+    assert torch.equal(dz, dz_ref) and torch.equal(loss_a, loss_b)
+    want = float(dz_ref.double().sum())
+    assert abs(float(bias) - want) <= 1e-6 * abs(want) + 1e-12
+
+    audio = torch.rand(2, 2, 128, 128, generator=g).to(DEV)
+    gtb = (30 * torch.rand(2, 1, 128, 128, generator=g)).to(DEV)
+    finals = []
+    for fused in (True, False):
+        if not fused:
+            monkeypatch.setenv('ADN_NO_FUSED_DZ', '1')
+        torch.manual_seed(0)
+        model = _build('unet_128', 64, depth_norm, torch.bfloat16)
+        model.train()
+        eng = model.engine()
+        tr = FusedTrainer(eng, 'Combined', 0.237, 0.637, 0.869, lr=0.002, clip_norm=1.0)
+        for _ in range(3):
+            tr.step(audio, gtb)
+        assert (eng.dz_target() is not None) == fused
+        torch.cuda.synchronize()
+        finals.append(eng.flat_p.detach().clone())
+    assert torch.equal(finals[0], finals[1])
+
+
 # ---- full-width (ngf 64, MFMA kernels) against numbers generated by the REFERENCE itself ------------------------------
 def _hash_key(key):
     h = 0
