@@ -522,6 +522,7 @@ class FusedTrainer:
         self._plan = None
         self._plan_after = None
         self._calls = 0
+        self._gout_valid, self._last_pred_gt = True, None
 
     def enable_launch_plan(self, after_steps=3):
         """Record the step's launches once (after ``after_steps`` eager steps) and replay the prebuilt ctypes
@@ -631,6 +632,16 @@ class FusedTrainer:
             return self._g_out
         return self._step_impl(audio, gt)
 
+    def loss_gradient(self):
+        """d loss / d prediction of the last step (diagnostics, tests).  When the fused loss kernel wrote the gradient of
+        the output's PRE-activation instead (adn_loss_finish_dz), it is recomputed here from that step's statistics."""
+        if not self._gout_valid:
+            pred, gt = self._last_pred_gt
+            K.loss_finish(pred, gt, self.scale, self.mask_mode, 1e-6, self.stats, self.criterion, self.l1_weight,
+                          self.silog_weight, self.silog_lambda, None, self.gout)
+            self._gout_valid = True
+        return self.gout
+
     def _step_impl(self, audio, gt):
         eng = self.engine
         if not self._ready or self._flat_id != (eng.flat_p.data_ptr() if eng.flat_p is not None else None):
@@ -666,6 +677,7 @@ class FusedTrainer:
         # under the reducer the norm is that of the all-reduced gradients, taken afterwards
         fused = (self.clip_norm is not None and self.ddp is None and getattr(eng, 'supports_fused_norm', False)
                  and eng.sq_all is not None)
+        self._gout_valid, self._last_pred_gt = not dz_ready, (pred, gt)
         if dz_ready:
             eng.backward(self.gout, fused_norm=fused, dz_ready=True)
         elif fused:

@@ -99,7 +99,12 @@ def test_fused_step_is_deterministic_and_tail_matches_torch():
     ref = 0.5 * (pp - gg).abs().mean() + 0.5 * torch.sqrt((d ** 2).mean() - 0.5 * d.mean() ** 2)
     assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref))
     ref.backward()
-    assert _rel(tr.gout, p.grad) <= 1e-5
+    assert _rel(tr.loss_gradient(), p.grad) <= 1e-5
+    target = eng.dz_target()
+    if target is not None:   # the loss kernel wrote d loss / d pre-activation directly (adn_loss_finish_dz): gout * act'(pred)
+        dz, _, final_act = target
+        dact = p.detach() * (1 - p.detach()) if final_act == 1 else (p.detach() > 0).float()
+        assert _rel(dz, p.grad * dact) <= 1e-5
     gflat = eng.flat_g.clone()                                   # gradients of this step (pre-clip values)
     norm = float(gflat.double().norm())
     gcl = gflat * min(1.0, 1.0 / (norm + 1e-6))

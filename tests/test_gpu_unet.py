@@ -99,7 +99,7 @@ def test_golden_reference_parity_f32(name, netG):
                       clip_norm=1.0)
     loss2, pred2 = tr.step(audio, gt)
     assert abs(loss2.item() - float(z['loss'])) <= 1e-4 * abs(float(z['loss']))
-    assert max_rel(tr.gout, z['pred_grad']) <= 1e-4
+    assert max_rel(tr.loss_gradient(), z['pred_grad']) <= 1e-4
     assert abs(tr.state[3].item() - float(z['grad_norm'])) <= 1e-3 * float(z['grad_norm'])
     sd2 = model2.state_dict()
     for k in sd2:
@@ -371,11 +371,11 @@ def test_unet64_reference_fixture(dtype):
     assert relp <= (1e-4 if f32 else BF16_PRED_REL_L1), relp
     assert abs(loss.item() - float(z['loss'])) <= (1e-5 if f32 else BF16_LOSS_REL) * abs(float(z['loss']))
     if f32:
-        assert max_rel(tr.gout, z['pred_grad']) <= 1e-4
+        assert max_rel(tr.loss_gradient(), z['pred_grad']) <= 1e-4
     else:                                   # SIlog's 1/pred term: a max-relative bound would be set by the smallest prediction
-        assert rel_l1(tr.gout, z['pred_grad']) <= 3e-2, rel_l1(tr.gout, z['pred_grad'])
+        assert rel_l1(tr.loss_gradient(), z['pred_grad']) <= 3e-2, rel_l1(tr.loss_gradient(), z['pred_grad'])
     print(f'{dtype}: eval32 rel-L1 {rel:.3e}, train pred rel-L1 {relp:.3e}, loss rel {abs(loss.item() - float(z["loss"])) / abs(float(z["loss"])):.3e}, '
-          f'dloss/dpred rel-L1 {rel_l1(tr.gout, z["pred_grad"]):.3e}')
+          f'dloss/dpred rel-L1 {rel_l1(tr.loss_gradient(), z["pred_grad"]):.3e}')
     names = [k for k, _ in model.named_parameters()]
     worst = {}
     for k, prm in model.named_parameters():
