@@ -222,6 +222,9 @@ _PROTOS = {
 _lib = None
 
 
+ABI_VERSION = 2      # adn_version() of the libadn.so these bindings describe (include/adn.h)
+
+
 def load():
     """Load libadn.so once; raises RuntimeError if it has not been built."""
     global _lib
@@ -237,6 +240,9 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
+    if lib.adn_version() != ABI_VERSION:     # the descriptor structs below must match the library's: never mix revisions
+        raise RuntimeError(f'{LIB_PATH} is ABI revision {lib.adn_version()}, this package binds revision {ABI_VERSION}: '
+                           'rebuild it (`make -C audio-depth-estimation_amd/csrc`)')
     _lib = lib
     return lib
 

@@ -14,4 +14,5 @@ void adn_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* adn_last_error(void) { return g_err; }
-extern "C" int adn_version(void) { return 1; }
+// 2: AdnWgradDesc grew (sq_partials); adn_wgrad_sq_count, adn_grad_norm_ranges, adn_loss_finish_dz added
+extern "C" int adn_version(void) { return 2; }

@@ -98,7 +98,8 @@ typedef struct {
 } AdnIgemmDesc;
 
 const char* adn_last_error(void);
-int adn_version(void);
+int adn_version(void);   /* ABI revision of this header: 2 (round 2: AdnWgradDesc.sq_partials, adn_wgrad_sq_count,
+                            adn_grad_norm_ranges, adn_loss_finish_dz) */
 
 /* Number of stats partial rows P the implicit GEMM will write for this descriptor. */
 int64_t adn_igemm_num_partials(const AdnIgemmDesc* d);
