@@ -1130,7 +1130,8 @@ inline void launch_patch(const KParams& kp, const Plan& pl, int geom, hipStream_
   if (pl.pair) {                 // 8 x 8 images, two per tile (every unet_256 layer of that level has >= 128 output columns)
     launch_patch1<128, ADN_GEMM_T2, false, true, true>(kp, pl, st);
   } else if (geom == ADN_GEMM_S2) {
-    if (pl.bn == 128) launch_patch1<128, ADN_GEMM_S2>(kp, pl, st);
+    if (pl.bn == 128 && kp.epi == ADN_EPI_BWD) launch_patch1<128, ADN_GEMM_S2>(kp, pl, st);
+    else if (pl.bn == 128) launch_patch1<128, ADN_GEMM_S2, false, false>(kp, pl, st);     // forward: no epilogue prefetch registers
     else launch_patch1<64, ADN_GEMM_S2>(kp, pl, st);
   } else if (geom == ADN_GEMM_T2) {
     if (pl.bn == 128) launch_patch1<128, ADN_GEMM_T2>(kp, pl, st);
