@@ -27,7 +27,7 @@ namespace {
 //                                               zero-record descriptor (every load dropped, zeros in LDS; wrong results)
 //   ADN_IGEMM_SKIP                              timing-only builds: bit 0 / 1 = the operand's LDS-DMA is not issued at all
 struct Tune {
-  int bm = 0, bn = 0, ns = 0, noa = 0, nob = 0, skip = 0, patch = 1, tall = 1, pair = 1, tinycap = 4, bn_t2 = 0, onepx = 1;
+  int bm = 0, bn = 0, ns = 0, noa = 0, nob = 0, skip = 0, patch = 1, tall = 1, pair = 1, tinycap = 4, bn_t2 = 0, onepx = 1, nopre = 0;
 };
 const Tune& tune() {
   static Tune t;
@@ -44,6 +44,7 @@ const Tune& tune() {
     if (const char* e = getenv("ADN_IGEMM_PAIR")) t.pair = atoi(e);
     if (const char* e = getenv("ADN_IGEMM_TINYCAP")) t.tinycap = atoi(e);
     if (const char* e = getenv("ADN_IGEMM_ONEPX")) t.onepx = atoi(e);
+    if (const char* e = getenv("ADN_IGEMM_NOPRE")) t.nopre = atoi(e);
     if (const char* e = getenv("ADN_IGEMM_BN_T2")) t.bn_t2 = atoi(e);
   });
   return t;
@@ -94,7 +95,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 //   256 x  64, 4x1 waves, 2 stages, 2 workgroups per CU        N = 64: every wave keeps a 64x64 sub-tile
 //   256 x 128, 4x2 waves, 3 stages, 1 workgroup per CU         long K: the DMA of steps s+1 and s+2 stays in
 //             flight across the per-step barrier (counted s_waitcnt vmcnt, raw s_barrier)
-template <typename T, int BM, int BN, int NWN, int GEOM, bool WIDE>
+// PRE = false: instantiation without the backward-epilogue prefetch registers (<= 96 VGPRs that are dead weight in every
+// forward and every split-K launch, where the prefetch is off at run time anyway: with them the kernel sits at ~250 of 256
+// VGPRs and the fragment reads of the K loop are issued just in time, see tools/isa_lds_waits.py)
+template <typename T, int BM, int BN, int NWN, int GEOM, bool WIDE, bool PRE = true>
 __global__ __launch_bounds__(BM * NWN, 2) void igemm_mfma_kernel(KParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins exist only in the device pass; the host needs the stub only
   constexpr int NTHR = BM * NWN;            // 64 threads per 64 x (BN/NWN) wave tile
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(BM * NWN, 2) void igemm_mfma_kernel(KParams p) {
   const int e_cg = tid % CPR;
   const int e_rsub = tid / CPR;
   const int e_n0 = tile_n * BN + e_cg * 8;
-  constexpr bool PRE_OK = sizeof(T) == 2;
+  constexpr bool PRE_OK = PRE && sizeof(T) == 2;
   const bool pre_on = PRE_OK && p.epi == ADN_EPI_BWD && p.nsplit == 1;
   u32x4_t pre_r[RPT], pre_o[RPT], pre_z[RPT];
   if constexpr (PRE_OK) {
@@ -1091,8 +1095,16 @@ int launch_mfma(const KParams& kp, const Plan& pl, hipStream_t st) {
   const int stage = ((BM_ == 256 && NWN == 2) ? 3 : 2) * (BM_ + BN) * 128;
   const int epil = BM_ * (BN + 4) * 4;
   const int lds = stage > epil ? stage : epil;
-  ADN_SET_LDS_ONCE(lds, &igemm_mfma_kernel<T, BM_, BN, NWN, GEOM, WIDE>);
   dim3 grid(pl.tiles_m * pl.tiles_n * pl.phases, 1, pl.nsplit);
+  if constexpr (sizeof(T) == 2) {
+    // (prepared at the end of round 2, NOT yet run on a GPU: off unless ADN_IGEMM_NOPRE=1; 116 instead of 214 VGPRs)
+    if (!(kp.epi == ADN_EPI_BWD && pl.nsplit == 1) && tune().nopre != 0) {     // the prefetch would be off at run time anyway
+      ADN_SET_LDS_ONCE(lds, &igemm_mfma_kernel<T, BM_, BN, NWN, GEOM, WIDE, false>);
+      hipLaunchKernelGGL((igemm_mfma_kernel<T, BM_, BN, NWN, GEOM, WIDE, false>), grid, dim3(BM_ * NWN), lds, st, kp);
+      return 0;
+    }
+  }
+  ADN_SET_LDS_ONCE(lds, &igemm_mfma_kernel<T, BM_, BN, NWN, GEOM, WIDE>);
   hipLaunchKernelGGL((igemm_mfma_kernel<T, BM_, BN, NWN, GEOM, WIDE>), grid, dim3(BM_ * NWN), lds, st, kp);
   return 0;
 }
