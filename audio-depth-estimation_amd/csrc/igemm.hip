@@ -27,7 +27,7 @@ namespace {
 //                                               zero-record descriptor (every load dropped, zeros in LDS; wrong results)
 //   ADN_IGEMM_SKIP                              timing-only builds: bit 0 / 1 = the operand's LDS-DMA is not issued at all
 struct Tune {
-  int bm = 0, bn = 0, ns = 0, noa = 0, nob = 0, skip = 0, patch = 1, tall = 1, pair = 1, tinycap = 4, bn_t2 = 0, onepx = 1, nopre = 0;
+  int bm = 0, bn = 0, ns = 0, noa = 0, nob = 0, skip = 0, patch = 1, tall = 1, pair = 1, tinycap = 4, bn_t2 = 0, onepx = 1, nopre = 0, ring = 1, ring_sched = 1;
 };
 const Tune& tune() {
   static Tune t;
@@ -46,6 +46,8 @@ const Tune& tune() {
     if (const char* e = getenv("ADN_IGEMM_ONEPX")) t.onepx = atoi(e);
     if (const char* e = getenv("ADN_IGEMM_NOPRE")) t.nopre = atoi(e);
     if (const char* e = getenv("ADN_IGEMM_BN_T2")) t.bn_t2 = atoi(e);
+    if (const char* e = getenv("ADN_IGEMM_RING")) t.ring = atoi(e);
+    if (const char* e = getenv("ADN_IGEMM_RING_SCHED")) t.ring_sched = atoi(e);
   });
   return t;
 }
@@ -850,6 +852,8 @@ __global__ __launch_bounds__(256, 2) void igemm_patch_kernel(KParams p) {
 #endif
 }
 
+#include "igemm_ring.h"
+
 // ---- generic direct path: any channel counts, one thread per output element, f32 slab out ----
 template <typename T, int GEOM>
 __global__ __launch_bounds__(256) void igemm_direct_kernel(KParams p) {
@@ -954,6 +958,7 @@ struct Plan {
   bool patch;       // patch-staged kernel (bf16, wide, unsplit, image 8 x 16 tileable)
   bool tall;        // its 16 x 16-pixel, 4 x 1-wave form (64 output columns, T2 / S1, image 16 x 16 tileable)
   bool pair;        // its two-images-per-tile form (S2 / T2, 8 x 8 small-grid images, 128 output columns, unsplit)
+  bool ring;        // ring-fed persistent kernel (igemm_ring.h): 16 x 16-pixel x bn tiles, one 8-wave workgroup per CU
   int wstride;
   int rb;
   int bm;
@@ -985,7 +990,7 @@ bool make_plan(const AdnIgemmDesc* d, Plan* pl) {
   const bool aligned = (pl->wide || narrow_ok) && (d->N % 64 == 0) && (d->seg[0].channels % 64 == 0) &&
                        (d->seg[1].channels % 64 == 0);
   pl->mfma = aligned;
-  pl->patch = pl->tall = pl->pair = false;
+  pl->patch = pl->tall = pl->pair = pl->ring = false;
   pl->onepx = false;
   if (!aligned) {
     pl->bn = 0;
@@ -1079,12 +1084,32 @@ bool make_plan(const AdnIgemmDesc* d, Plan* pl) {
     pl->bm = pl->tall ? 256 : 128;
     pl->tiles_m = (int)(msmall / pl->bm);
   }
+  // ring-fed persistent kernel: bf16, wide, unsplit, 16 x 16-pixel tiles, Z_STATS / BWD epilogues, a multiple of 8 K-steps
+  // per tile (S2: always; T2: Cin % 128 == 0), every 32-channel chunk inside one source.  The number of partial rows is
+  // reported for the ring kernel whenever the SHAPE qualifies (queries do not know the epilogue; only the two epilogues
+  // that run on it write partial rows).
+  pl->ring = false;
+  int64_t ring_rows = -1;
+  if (d->dtype == ADN_BF16 && pl->wide && ns == 1 && !pl->pair && (d->geom == ADN_GEMM_S2 || d->geom == ADN_GEMM_T2) &&
+      d->Hs % 16 == 0 && d->Ws % 16 == 0 && d->N % 128 == 0 && (d->geom == ADN_GEMM_S2 || Cin % 128 == 0) && tn.ring != 0) {
+    ring_rows = msmall / 256 * pl->phases;
+    if (d->epi == ADN_EPI_Z_STATS || d->epi == ADN_EPI_BWD) {
+      const int64_t t128 = msmall / 256 * (d->N / 128) * pl->phases;
+      const int rbn = (tn.ring == 64 || (tn.ring != 128 && t128 < 192)) ? 64 : 128;    // too few 128-column tiles to fill the chip: 64
+      pl->ring = true;
+      pl->patch = pl->tall = false;
+      pl->bm = 256;
+      pl->bn = rbn;
+      pl->tiles_m = (int)(msmall / 256);
+      pl->tiles_n = d->N / rbn;
+    }
+  }
   pl->rb = reduce_rows(pl->mout, d->N);
   if (ns > 1) {
     pl->partial_rows = adn_cdiv(pl->mout, pl->rb);
     pl->slab_bytes = (int64_t)ns * pl->mout * d->N * 4;
   } else {
-    pl->partial_rows = (int64_t)pl->tiles_m * pl->phases;
+    pl->partial_rows = ring_rows >= 0 ? ring_rows : (int64_t)pl->tiles_m * pl->phases;
     pl->slab_bytes = 0;
   }
   return true;
@@ -1158,6 +1183,43 @@ inline void launch_patch(const KParams& kp, const Plan& pl, int geom, hipStream_
   }
 }
 
+inline int device_cus() {
+  static int n = 0;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount;
+    if (n <= 0) n = 256;
+  });
+  return n;
+}
+
+template <int GEOM, int BN, int SCHED>
+void launch_ring1(const KParams& kp, const Plan& pl, hipStream_t st) {
+  constexpr bool S2 = GEOM == ADN_GEMM_S2;
+  constexpr int lds = (S2 ? 2 * 40 : 4 * 20) * 1024 + 4 * 2 * BN * 64 + 8 * BN * 4;
+  ADN_SET_LDS_ONCE(lds, &igemm_ring_kernel<GEOM, BN, SCHED>);
+  const int ntiles = pl.tiles_m * pl.tiles_n * pl.phases;
+  const int cus = device_cus();
+  const int nwgs = ntiles < cus ? ntiles : cus;
+  hipLaunchKernelGGL((igemm_ring_kernel<GEOM, BN, SCHED>), dim3(nwgs), dim3(512), lds, st, kp, ntiles, nwgs);
+}
+template <int GEOM, int BN>
+void launch_ring2(const KParams& kp, const Plan& pl, hipStream_t st) {
+  if (tune().ring_sched) launch_ring1<GEOM, BN, 1>(kp, pl, st);
+  else launch_ring1<GEOM, BN, 0>(kp, pl, st);
+}
+inline void launch_ring(const KParams& kp, const Plan& pl, int geom, hipStream_t st) {
+  if (geom == ADN_GEMM_S2) {
+    if (pl.bn == 128) launch_ring2<ADN_GEMM_S2, 128>(kp, pl, st);
+    else launch_ring2<ADN_GEMM_S2, 64>(kp, pl, st);
+  } else {
+    if (pl.bn == 128) launch_ring2<ADN_GEMM_T2, 128>(kp, pl, st);
+    else launch_ring2<ADN_GEMM_T2, 64>(kp, pl, st);
+  }
+}
+
 template <typename T>
 int run(const AdnIgemmDesc* d, const Plan& pl, hipStream_t st) {
   KParams kp;
@@ -1192,7 +1254,10 @@ int run(const AdnIgemmDesc* d, const Plan& pl, hipStream_t st) {
   kp.rec_a = tune().noa ? 0u : 0x7ffffff0u;
   kp.rec_b = tune().nob ? 0u : 0x7ffffff0u;
   kp.skip = tune().skip;
-  if (pl.mfma && pl.patch) {
+  if (pl.mfma && pl.ring) {
+    if constexpr (sizeof(T) == 2) launch_ring(kp, pl, d->geom, st);
+    ADN_CHECK_LAUNCH();
+  } else if (pl.mfma && pl.patch) {
     if constexpr (sizeof(T) == 2) launch_patch(kp, pl, d->geom, st);
     ADN_CHECK_LAUNCH();
   } else if (pl.mfma) {

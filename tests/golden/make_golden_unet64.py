@@ -1,7 +1,8 @@
 """Reference-generated fixture for the FULL-WIDTH U-Net (unet_256, ngf 64: the MFMA path of libadn), made by importing the
 reference in the build container:
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_unet64.py
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_unet64.py        # unet256_ngf64.npz (B = 4 step, B = 32 eval)
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_unet64.py b32    # unet256_ngf64_b32.npz (B = 32 TRAIN step)
 
 Entry points exercised (file:line in /root/reference): models/unetbaseline_model.py:84 define_G; utils_loss.py:9
 SIlogLoss; train.py:646-691 (masked Combined loss, backward, clip_grad_norm_(1.0), AdamW(lr) step).
@@ -108,5 +109,58 @@ def main():
     print('unet256_ngf64 loss', loss.item(), 'grad_norm', tn.item(), 'bytes', os.path.getsize(path))
 
 
+def main_b32():
+    """The HEADLINE shape: one full train step at B = 32 (BASELINE.json configs[1]) -- the real tilings, split-K factors
+    and slab sums of every backward kernel.  Samples only (the file stays < 1 MB): 8192 points of the train-mode
+    prediction and of d loss / d pred, per-tensor gradient norms + 512-element samples, the clipped norm, parameter
+    samples after the AdamW step, all BatchNorm running statistics after the step."""
+    torch.set_num_threads(8)
+    cfg = SimpleNamespace(dataset=SimpleNamespace(depth_norm=False, max_depth=30.0))
+    torch.manual_seed(0)
+    model = define_G(cfg, input_nc=2, output_nc=1, ngf=64, netG='unet_256', norm='batch', use_dropout=False,
+                     init_type='normal', init_gain=0.02, gpu_ids=[])
+    with torch.no_grad():
+        model.model.model[3].bias.fill_(1.0)
+    out = {}
+    audio, gt = synth_batch(32, 256, 1234)
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=LR)
+    opt.zero_grad()
+    pred = model(audio)
+    valid = gt != 0.0
+    loss = L1_W * torch.nn.L1Loss()(pred[valid], gt[valid]) + SILOG_W * SIlogLoss(lambda_scale=SILOG_LAMBDA)(pred[valid], gt[valid])
+    pred.retain_grad()
+    loss.backward()
+    g = torch.Generator().manual_seed(77)
+    idx = torch.randint(0, pred.numel(), (8192,), generator=g)
+    out['idx'] = idx.numpy()
+    out['pred_val'] = pred.detach().view(-1)[idx].numpy()
+    out['pred_absmean'] = np.float64(pred.detach().abs().mean().item())
+    out['pred_grad_val'] = pred.grad.detach().view(-1)[idx].numpy()
+    out['pred_grad_l1'] = np.float64(pred.grad.detach().double().abs().sum().item())
+    out['loss'] = np.float64(loss.item())
+    for k, prm in model.named_parameters():
+        gflat = prm.grad.detach().view(-1)
+        si = sample_idx(gflat.numel(), k)
+        out['gnorm/' + k] = np.float64(gflat.double().norm().item())
+        out['gsample/' + k] = gflat[si].numpy()
+    tn = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
+    out['grad_norm'] = np.float64(tn.item())
+    opt.step()
+    for k, prm in model.named_parameters():
+        si = sample_idx(prm.numel(), k)
+        out['p1sample/' + k] = prm.detach().view(-1)[si].numpy()
+    for k, v in model.state_dict().items():
+        if 'running_' in k or 'num_batches' in k:
+            out['sd1/' + k] = v.detach().clone().numpy()
+    out['hyper'] = np.array([LR, 30.0, L1_W, SILOG_W, SILOG_LAMBDA], dtype=np.float64)
+    path = os.path.join(HERE, 'unet256_ngf64_b32.npz')
+    np.savez_compressed(path, **out)
+    print('unet256_ngf64_b32 loss', loss.item(), 'grad_norm', tn.item(), 'bytes', os.path.getsize(path))
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'b32':
+        main_b32()
+    else:
+        main()

@@ -264,3 +264,89 @@ def test_distillation_trainers_full_size_determinism(kind):
         finals.append((float(loss), m.engine().flat_p.clone()))
         del m, tr
     assert finals[0][0] == finals[1][0] and torch.equal(finals[0][1], finals[1][1])
+
+
+# ---- reference-generated numbers at the headline size (tests/golden/make_golden_unet64.py b32) -----------------------
+def _hash_key(key):
+    h = 0
+    for ch in key:
+        h = (h * 131 + ord(ch)) % (2 ** 31 - 1)
+    return h
+
+
+def _sample_idx(numel, key, ns=512):
+    g = torch.Generator().manual_seed(_hash_key(key))
+    return torch.randint(0, numel, (min(ns, numel),), generator=g)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_b32_train_step_against_the_reference(dtype):
+    """ONE full train step of unet_256 ngf 64 at B = 32 (BASELINE configs[1]) against numbers produced by the reference's
+    own define_G / SIlogLoss / clip_grad_norm_ / AdamW on the CPU (unet256_ngf64_b32.npz): prediction and d loss / d pred
+    samples, loss, every gradient tensor (norm + 512 samples), clipped norm, BatchNorm running statistics, AdamW step.
+    This is "right", not just "linear and repeatable", at the tilings / split-K factors / slab sums that are benchmarked.
+    f32: prediction rel-L1 <= 1e-4 (north_star), gradients <= 5e-3 of the tensor norm (sampled rel-L2 <= 2e-2: the
+    reference's own fp32 noise floor at this depth).  bf16 bounds are stated against the reference too."""
+    import os
+
+    import numpy as np
+    from audio_depth_estimation_amd.engine import FusedTrainer
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'unet256_ngf64_b32.npz'))
+    lr, max_depth, l1w, sw, lam = [float(v) for v in z['hyper']]
+    f32 = dtype == torch.float32
+    model = _model(dtype)
+    with torch.no_grad():
+        model.model.model[3].bias.fill_(1.0)
+    model.train()
+    eng = model.engine()
+    audio, gt = _batch()                                     # same seed / construction as the generator's synth_batch(32, 256, 1234)
+    tr = FusedTrainer(eng, 'Combined', l1w, sw, lam, max_depth=max_depth, optimizer='AdamW', lr=lr, clip_norm=1.0)
+    loss, pred = tr.step(audio, gt)
+    idx = torch.from_numpy(z['idx'])
+    got = pred.reshape(-1).float().cpu()[idx]
+    ref = torch.from_numpy(z['pred_val'])
+    relp = float((got - ref).abs().sum() / ref.abs().sum())
+    assert relp <= (1e-4 if f32 else 1e-2), relp
+    lrel = abs(loss.item() - float(z['loss'])) / abs(float(z['loss']))
+    assert lrel <= (1e-5 if f32 else 1e-3), lrel
+    dg = tr.loss_gradient().reshape(-1).float().cpu()[idx]
+    dref = torch.from_numpy(z['pred_grad_val'])
+    reld = float((dg - dref).abs().sum() / dref.abs().sum())
+    assert reld <= (1e-4 if f32 else 3e-2), reld
+    names = [k for k, _ in model.named_parameters()]
+    worst = {}
+    for k, prm in model.named_parameters():
+        gflat = eng.grad_view(prm).detach().float().cpu().reshape(-1)
+        gn_ref = float(z['gnorm/' + k])
+        if gn_ref < 1e-12:
+            continue
+        si = _sample_idx(gflat.numel(), k)
+        rms = gn_ref / (gflat.numel() ** 0.5)
+        err = float((gflat[si] - torch.from_numpy(z['gsample/' + k])).norm() / (len(si) ** 0.5)) / rms
+        nerr = abs(float(gflat.double().norm()) - gn_ref) / gn_ref
+        worst[k] = (err, nerr)
+        if f32:
+            assert err <= 2e-2 and nerr <= 5e-3, (k, err, nerr)
+        else:
+            assert err <= (0.08 if k in names[-4:] else 0.5), (k, err)
+    print(f'{dtype}: pred rel-L1 {relp:.3e} loss rel {lrel:.3e} dloss/dpred rel-L1 {reld:.3e}; worst gradients',
+          sorted(worst.items(), key=lambda kv: -kv[1][0])[:4])
+    gn = float(z['grad_norm'])
+    assert abs(tr.state[3].item() - gn) <= (2e-3 if f32 else 5e-2) * gn
+    if f32:
+        for k, prm in model.named_parameters():
+            si = _sample_idx(prm.numel(), k)
+            gs = torch.from_numpy(z['gsample/' + k]).abs()
+            m = gs > 1e-2 * gs.max()                       # Adam's sign-like step is ill-conditioned where g ~ 0
+            d = (prm.detach().cpu().reshape(-1)[si] - torch.from_numpy(z['p1sample/' + k])).abs()[m]
+            assert float(d.max()) <= 0.05 * lr, (k, float(d.max()) / lr)
+    sd = model.state_dict()
+    for k in z.files:
+        if not k.startswith('sd1/'):
+            continue
+        ref_v = torch.from_numpy(z[k])
+        gotv = sd[k[4:]].cpu()
+        if ref_v.dtype == torch.int64:
+            assert int(gotv) == int(ref_v), k
+        else:
+            assert float((gotv - ref_v).abs().max()) <= (1e-4 if f32 else 2e-2) * float(ref_v.abs().max()) + 1e-6, k

@@ -256,7 +256,10 @@ def test_wgrad_norm_partials(dtype, shape):
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('shape', [(2, 64, 0, 128, 16), (3, 128, 0, 128, 2), (2, 6, 0, 10, 4), (8, 64, 0, 128, 64),
-                                   (16, 64, 0, 128, 64)])
+                                   (16, 64, 0, 128, 64),
+                                   (20, 64, 0, 128, 64),     # ring kernel, 128-column tiles, 320 tiles on <= 256 workgroups
+                                   (16, 128, 0, 256, 32),    # ring kernel, 64-column tiles (too few 128-column ones)
+                                   (12, 64, 0, 384, 32)])    # ring kernel, 64-column tiles, 6 column tiles per pixel tile, 288 tiles
 def test_epilogue_z_stats_and_bn(dtype, shape):
     """Z_STATS epilogue + adn_bn_fwd_finalize + adn_bn_act == conv -> BatchNorm2d(train) -> LeakyReLU / ReLU."""
     B, C0, _, N, Hs = shape
@@ -292,7 +295,9 @@ def test_epilogue_z_stats_and_bn(dtype, shape):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize('shape', [(2, 128, 0, 64, 8), (2, 10, 0, 6, 4), (8, 128, 0, 64, 64), (16, 128, 0, 64, 64)])
+@pytest.mark.parametrize('shape', [(2, 128, 0, 64, 8), (2, 10, 0, 6, 4), (8, 128, 0, 64, 64), (16, 128, 0, 64, 64),
+                                   (16, 128, 0, 128, 64),    # ring kernel: S2 BWD with two 128-channel segments, T2 BWD accumulating
+                                   (20, 128, 0, 64, 64)])    # ring kernel: the two segments inside ONE 128-column tile, 320 tiles
 def test_epilogue_bwd_two_segments(dtype, shape):
     """convT dgrad with ReLU mask, split into a skip segment (no stats) and an up segment (BN-bwd stats),
     then accumulate a second contribution with a LeakyReLU mask."""
@@ -332,6 +337,32 @@ def test_epilogue_bwd_two_segments(dtype, shape):
     k.igemm(dtype, 1, B, Hs // 2, Hs // 2, nhwc(dzs, dtype), None, t2, Chalf, 3,
             [k.Seg(Chalf, out0=g0, ref=nhwc(ref_act[0], dtype), slope=0.2, accumulate=True)], ws2)
     assert rel_err(from_nhwc(g0), acc_ref) <= 2 * TOL_T_OUT[dtype]
+
+
+@pytest.mark.parametrize('shape', [(8, 64, 64, 128, 32),      # ring kernel T2, 64-column tiles, two gathered sources
+                                   (16, 128, 128, 128, 32),   # ring kernel T2, 128-column tiles
+                                   (5, 128, 0, 256, 64),      # ring kernel T2, 320 pixel tiles x 4 phases x 2 column tiles
+                                   (2, 64, 64, 128, 16)])     # (split-K path for comparison)
+def test_convT_z_stats_t2(shape):
+    """Z_STATS epilogue of the transposed-conv geometry in bf16 (the up path's forward): z and the BatchNorm column sums
+    against ConvTranspose2d; the large shapes run the ring-fed persistent kernel (igemm_ring.h)."""
+    dtype = torch.bfloat16
+    B, C0, C1, N, Hs = shape
+    torch.manual_seed(11)
+    k = K()
+    x = rounded(torch.randn(B, C0 + C1, Hs, Hs), dtype)
+    w = rounded(torch.randn(C0 + C1, N, 4, 4) * 0.1, dtype)
+    zref = F.conv_transpose2d(x, w, stride=2, padding=1)
+    _, t2 = pack(w, dtype)
+    in0 = nhwc(x[:, :C0], dtype)
+    in1 = nhwc(x[:, C0:], dtype) if C1 else None
+    P, ws = ws_for(dtype, 1, B, Hs, Hs, C0, C1, N, [N])
+    z = torch.empty(B, 2 * Hs, 2 * Hs, N, dtype=dtype, device=DEV)
+    partials = torch.zeros(P, 2, N, dtype=torch.float32, device=DEV)
+    k.igemm(dtype, 1, B, Hs, Hs, in0, in1, t2, N, 1, [k.Seg(N, out0=z, partials=partials)], ws)
+    assert rel_err(from_nhwc(z), zref) <= TOL_T_OUT[dtype]
+    assert rel_err(partials[:, 0].double().sum(0).float(), zref.sum((0, 2, 3))) <= 2e-4
+    assert rel_err(partials[:, 1].double().sum(0).float(), (zref * zref).sum((0, 2, 3))) <= 2e-4
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
