@@ -88,6 +88,7 @@ class AdnDistillSmall(C.Structure):
 _PROTOS = {
     'adn_last_error': (C.c_char_p, []),
     'adn_version': (C.c_int, []),
+    'adn_debug_poison_lds': (C.c_int, [c_void_p]),
     'adn_igemm_num_partials': (c_int64, [C.POINTER(AdnIgemmDesc)]),
     'adn_igemm_workspace_bytes': (c_int64, [C.POINTER(AdnIgemmDesc)]),
     'adn_igemm': (C.c_int, [C.POINTER(AdnIgemmDesc), c_void_p]),
@@ -263,9 +264,15 @@ def check(rc: int, what: str = ''):
 RECORD = None
 
 
+_POISON = bool(os.environ.get('ADN_LDS_POISON'))      # debugging aid: see adn_debug_poison_lds in include/adn.h
+
+
 def call(name: str, *args):
     """Call an int-returning entry point and raise on error."""
     fn = getattr(load(), name)
+    if _POISON:
+        import torch
+        check(load().adn_debug_poison_lds(C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'adn_debug_poison_lds')
     check(fn(*args), name)
     if RECORD is not None:
         RECORD.append((fn, args, name, {}))

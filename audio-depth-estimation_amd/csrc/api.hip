@@ -16,3 +16,26 @@ void adn_set_error(const char* fmt, ...) {
 extern "C" const char* adn_last_error(void) { return g_err; }
 // 2: AdnWgradDesc grew (sq_partials); adn_wgrad_sq_count, adn_grad_norm_ranges, adn_loss_finish_dz added
 extern "C" int adn_version(void) { return 2; }
+
+
+// ---- debugging aid: poison the LDS of every CU ----------------------------------------------------------------------
+// LDS keeps its bytes from one kernel to the next.  A kernel that READS LDS it never wrote gives results that depend on
+// what ran before it on that CU; this launch (ADN_LDS_POISON=1 in the Python binding: in front of every call) fills all
+// 160 KiB of every CU with 0xFFFFFFFF (NaN as f32 and as a bf16 pair), so such a read shows up as NaN in the outputs.
+namespace {
+__global__ __launch_bounds__(1024) void lds_poison_kernel(int bytes) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  for (int i = threadIdx.x * 16; i < bytes; i += 1024 * 16) *reinterpret_cast<u32x4_t*>(smem + i) = u32x4_t{~0u, ~0u, ~0u, ~0u};
+  __syncthreads();
+  // keep the workgroup on its CU long enough that the 2048 workgroups spread over all of them
+  for (int k = 0; k < 16; ++k) __builtin_amdgcn_s_sleep(127);
+}
+}  // namespace
+
+extern "C" int adn_debug_poison_lds(void* stream) {
+  constexpr int bytes = 160 * 1024;
+  ADN_SET_LDS_ONCE(bytes, &lds_poison_kernel);
+  hipLaunchKernelGGL(lds_poison_kernel, dim3(2048), dim3(1024), bytes, reinterpret_cast<hipStream_t>(stream), bytes);
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}

@@ -27,7 +27,7 @@ namespace {
 //                                               zero-record descriptor (every load dropped, zeros in LDS; wrong results)
 //   ADN_IGEMM_SKIP                              timing-only builds: bit 0 / 1 = the operand's LDS-DMA is not issued at all
 struct Tune {
-  int bm = 0, bn = 0, ns = 0, noa = 0, nob = 0, skip = 0, patch = 1, tall = 1, pair = 1, tinycap = 4, bn_t2 = 0, onepx = 1, nopre = 0, ring = 1, ring_sched = 1;
+  int bm = 0, bn = 0, ns = 0, noa = 0, nob = 0, skip = 0, patch = 1, tall = 1, pair = 1, tinycap = 4, bn_t2 = 0, onepx = 1, nopre = 0, ring = 1, ring_sched = 1, ring_epi = 0, ring_geom = -1, ring_hs = 0;
 };
 const Tune& tune() {
   static Tune t;
@@ -48,6 +48,9 @@ const Tune& tune() {
     if (const char* e = getenv("ADN_IGEMM_BN_T2")) t.bn_t2 = atoi(e);
     if (const char* e = getenv("ADN_IGEMM_RING")) t.ring = atoi(e);
     if (const char* e = getenv("ADN_IGEMM_RING_SCHED")) t.ring_sched = atoi(e);
+    if (const char* e = getenv("ADN_IGEMM_RING_EPI")) t.ring_epi = atoi(e);      // A/B: ring kernel only for this epilogue (1 | 3)
+    if (const char* e = getenv("ADN_IGEMM_RING_GEOM")) t.ring_geom = atoi(e);    // A/B: ring kernel only for this geometry (0 | 1)
+    if (const char* e = getenv("ADN_IGEMM_RING_HS")) t.ring_hs = atoi(e);        // A/B: ring kernel only at this small-grid height
   });
   return t;
 }
@@ -1085,31 +1088,28 @@ bool make_plan(const AdnIgemmDesc* d, Plan* pl) {
     pl->tiles_m = (int)(msmall / pl->bm);
   }
   // ring-fed persistent kernel: bf16, wide, unsplit, 16 x 16-pixel tiles, Z_STATS / BWD epilogues, a multiple of 8 K-steps
-  // per tile (S2: always; T2: Cin % 128 == 0), every 32-channel chunk inside one source.  The number of partial rows is
-  // reported for the ring kernel whenever the SHAPE qualifies (queries do not know the epilogue; only the two epilogues
-  // that run on it write partial rows).
+  // per tile (S2: always; T2: Cin % 128 == 0), every 32-channel chunk inside one source.  (The plan -- and with it the number
+  // of partial rows -- depends on the epilogue: adn_igemm_num_partials must be asked with the epilogue of the launch.)
   pl->ring = false;
-  int64_t ring_rows = -1;
   if (d->dtype == ADN_BF16 && pl->wide && ns == 1 && !pl->pair && (d->geom == ADN_GEMM_S2 || d->geom == ADN_GEMM_T2) &&
-      d->Hs % 16 == 0 && d->Ws % 16 == 0 && d->N % 128 == 0 && (d->geom == ADN_GEMM_S2 || Cin % 128 == 0) && tn.ring != 0) {
-    ring_rows = msmall / 256 * pl->phases;
-    if (d->epi == ADN_EPI_Z_STATS || d->epi == ADN_EPI_BWD) {
-      const int64_t t128 = msmall / 256 * (d->N / 128) * pl->phases;
-      const int rbn = (tn.ring == 64 || (tn.ring != 128 && t128 < 192)) ? 64 : 128;    // too few 128-column tiles to fill the chip: 64
-      pl->ring = true;
-      pl->patch = pl->tall = false;
-      pl->bm = 256;
-      pl->bn = rbn;
-      pl->tiles_m = (int)(msmall / 256);
-      pl->tiles_n = d->N / rbn;
-    }
+      d->Hs % 16 == 0 && d->Ws % 16 == 0 && d->N % 128 == 0 && (d->geom == ADN_GEMM_S2 || Cin % 128 == 0) && tn.ring != 0 &&
+      (d->epi == ADN_EPI_Z_STATS || d->epi == ADN_EPI_BWD) && (tn.ring_epi == 0 || tn.ring_epi == d->epi) &&
+      (tn.ring_geom < 0 || tn.ring_geom == d->geom) && (tn.ring_hs == 0 || tn.ring_hs == d->Hs)) {
+    const int64_t t128 = msmall / 256 * (d->N / 128) * pl->phases;
+    const int rbn = (tn.ring == 64 || (tn.ring != 128 && t128 < 192)) ? 64 : 128;    // too few 128-column tiles to fill the chip: 64
+    pl->ring = true;
+    pl->patch = pl->tall = false;
+    pl->bm = 256;
+    pl->bn = rbn;
+    pl->tiles_m = (int)(msmall / 256);
+    pl->tiles_n = d->N / rbn;
   }
   pl->rb = reduce_rows(pl->mout, d->N);
   if (ns > 1) {
     pl->partial_rows = adn_cdiv(pl->mout, pl->rb);
     pl->slab_bytes = (int64_t)ns * pl->mout * d->N * 4;
   } else {
-    pl->partial_rows = ring_rows >= 0 ? ring_rows : (int64_t)pl->tiles_m * pl->phases;
+    pl->partial_rows = (int64_t)pl->tiles_m * pl->phases;
     pl->slab_bytes = 0;
   }
   return true;

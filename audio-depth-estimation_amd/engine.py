@@ -144,14 +144,16 @@ class UNetEngine(FlatParamEngine):
             c_up0 = cd_out
             c_up1 = cu_in - cd_out
             edge0 = i == 0 and self.edge_path
-            pd, w1 = (0, 0) if edge0 else K.igemm_query(T, GEMM_S2, B, hs, wsz, cd_in_p, 0, cd_out, [cd_out])   # Li fwd
+            pd, w1 = (0, 0) if edge0 else K.igemm_query(T, GEMM_S2, B, hs, wsz, cd_in_p, 0, cd_out, [cd_out],   # Li fwd
+                                                       epi=EPI_Z_STATS if lv['bn_d'] is not None else EPI_ACT)
             if i == 0 and self.n1_path:
                 pu, w2 = 0, K.convt_n1_workspace_bytes(B, hs, wsz)                                  # D0 fwd
             else:
-                pu, w2 = K.igemm_query(T, GEMM_T2, B, hs, wsz, c_up0, c_up1, cu_out, [cu_out])     # Di fwd
+                pu, w2 = K.igemm_query(T, GEMM_T2, B, hs, wsz, c_up0, c_up1, cu_out, [cu_out],     # Di fwd
+                                        epi=EPI_Z_STATS if lv['bn_u'] is not None else EPI_FINAL)
             pgu, w3 = (0, 0) if edge0 else K.igemm_query(T, GEMM_S2, B, hs, wsz, cu_out_p, 0, cu_in,   # Di dgrad
-                                                         [c_up0, c_up1] if c_up1 else [c_up0])
-            pgd, w4 = (0, 0) if i == 0 else K.igemm_query(T, GEMM_T2, B, hs, wsz, cd_out, 0, cd_in, [cd_in])  # Li dgrad
+                                                         [c_up0, c_up1] if c_up1 else [c_up0], epi=EPI_BWD)
+            pgd, w4 = (0, 0) if i == 0 else K.igemm_query(T, GEMM_T2, B, hs, wsz, cd_out, 0, cd_in, [cd_in], epi=EPI_BWD)  # Li dgrad
             w5 = 0 if edge0 else K.wgrad_workspace_bytes(T, B, hs, wsz, cd_out, 0, cd_in_p, 0,
                                                          cd_in if cd_in_p != cd_in else 0)
             w6 = 0 if edge0 else K.wgrad_workspace_bytes(T, B, hs, wsz, c_up0, c_up1, cu_out_p, 0,

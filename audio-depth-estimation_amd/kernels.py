@@ -97,18 +97,19 @@ def _igemm_desc(dtype, geom, B, Hs, Ws, in0, in1, w, N, epi, segs, workspace=Non
     return d
 
 
-def igemm_query(dtype, geom, B, Hs, Ws, C0, C1, N, seg_channels, ks=0):
-    """(num stats partial rows, workspace bytes) for a shape, without touching the GPU."""
+def igemm_query(dtype, geom, B, Hs, Ws, C0, C1, N, seg_channels, ks=0, epi=EPI_RAW):
+    """(num stats partial rows, workspace bytes) for a shape, without touching the GPU.  ``epi``: the epilogue the launch
+    will use -- the kernel choice (and with it the number of partial rows of the Z_STATS / BWD epilogues) depends on it."""
     d = AdnIgemmDesc()
     d.ks = ks
     d.dtype, d.geom, d.B, d.Hs, d.Ws, d.C0, d.C1, d.N = dtype_code(dtype), geom, B, Hs, Ws, C0, C1, N
     d.in0 = d.w = 1
     d.in1 = 1 if C1 else None
-    d.epi = EPI_RAW
+    d.epi = epi
     d.seg[0].channels = seg_channels[0]
-    d.seg[0].out0 = 1
+    d.seg[0].out0 = d.seg[0].ref = 1                    # (dummy non-null operands: the query only validates and plans)
     d.seg[1].channels = seg_channels[1] if len(seg_channels) > 1 else 0
-    d.seg[1].out0 = 1
+    d.seg[1].out0 = d.seg[1].ref = 1
     lib = _lib.load()
     p = lib.adn_igemm_num_partials(C.byref(d))
     wsb = lib.adn_igemm_workspace_bytes(C.byref(d))

@@ -100,6 +100,10 @@ typedef struct {
 const char* adn_last_error(void);
 int adn_version(void);   /* ABI revision of this header: 2 (round 2: AdnWgradDesc.sq_partials, adn_wgrad_sq_count,
                             adn_grad_norm_ranges, adn_loss_finish_dz) */
+/* Debugging aid: fills the LDS of every CU with 0xFFFFFFFF so that a kernel reading LDS it never wrote produces NaN
+ * instead of values that depend on the previous kernel (the Python binding calls it in front of every launch when
+ * ADN_LDS_POISON=1).  No counterpart in the reference. */
+int adn_debug_poison_lds(void* stream);
 
 /* Number of stats partial rows P the implicit GEMM will write for this descriptor. */
 int64_t adn_igemm_num_partials(const AdnIgemmDesc* d);

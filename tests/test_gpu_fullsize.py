@@ -285,18 +285,22 @@ def test_b32_train_step_against_the_reference(dtype):
     own define_G / SIlogLoss / clip_grad_norm_ / AdamW on the CPU (unet256_ngf64_b32.npz): prediction and d loss / d pred
     samples, loss, every gradient tensor (norm + 512 samples), clipped norm, BatchNorm running statistics, AdamW step.
     This is "right", not just "linear and repeatable", at the tilings / split-K factors / slab sums that are benchmarked.
-    f32: prediction rel-L1 <= 1e-4 (north_star), gradients <= 5e-3 of the tensor norm (sampled rel-L2 <= 2e-2: the
-    reference's own fp32 noise floor at this depth).  bf16 bounds are stated against the reference too."""
+    f32: prediction rel-L1 <= 1e-4 (north_star; measured 1.3e-7), gradients <= 5e-3 of the tensor norm (sampled rel-L2 <= 2e-2:
+    the reference's own fp32 noise floor at this depth; measured <= 5.8e-3).  bf16, against the reference too: prediction
+    rel-L1 <= 3e-3 (5.1e-4), loss 1e-4, d loss / d pred 5e-3 (4.6e-4), every gradient tensor: sampled rel-L2 <= 0.4 (worst
+    0.31, the innermost BatchNorm affine; <= 0.08 on the four outermost tensors) and norm within 3 % (<= 1.4 %).
+    The fixture's output bias is 4.0: with 2 M predicted pixels and the bias at 1.0 a few land in (0, 1e-3), where SIlog's
+    1 / pred lets ONE pixel set every gradient norm -- two bf16 runs one rounding apart then differ 5x."""
     import os
 
     import numpy as np
     from audio_depth_estimation_amd.engine import FusedTrainer
     z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'unet256_ngf64_b32.npz'))
-    lr, max_depth, l1w, sw, lam = [float(v) for v in z['hyper']]
+    lr, max_depth, l1w, sw, lam, bias0 = [float(v) for v in z['hyper']]
     f32 = dtype == torch.float32
     model = _model(dtype)
     with torch.no_grad():
-        model.model.model[3].bias.fill_(1.0)
+        model.model.model[3].bias.fill_(bias0)        # keeps every prediction away from SIlog's 1 / pred singularity (generator script)
     model.train()
     eng = model.engine()
     audio, gt = _batch()                                     # same seed / construction as the generator's synth_batch(32, 256, 1234)
@@ -306,13 +310,13 @@ def test_b32_train_step_against_the_reference(dtype):
     got = pred.reshape(-1).float().cpu()[idx]
     ref = torch.from_numpy(z['pred_val'])
     relp = float((got - ref).abs().sum() / ref.abs().sum())
-    assert relp <= (1e-4 if f32 else 1e-2), relp
+    assert relp <= (1e-4 if f32 else 3e-3), relp
     lrel = abs(loss.item() - float(z['loss'])) / abs(float(z['loss']))
-    assert lrel <= (1e-5 if f32 else 1e-3), lrel
+    assert lrel <= (1e-5 if f32 else 1e-4), lrel
     dg = tr.loss_gradient().reshape(-1).float().cpu()[idx]
     dref = torch.from_numpy(z['pred_grad_val'])
     reld = float((dg - dref).abs().sum() / dref.abs().sum())
-    assert reld <= (1e-4 if f32 else 3e-2), reld
+    assert reld <= (1e-4 if f32 else 5e-3), reld
     names = [k for k, _ in model.named_parameters()]
     worst = {}
     for k, prm in model.named_parameters():
@@ -325,21 +329,22 @@ def test_b32_train_step_against_the_reference(dtype):
         err = float((gflat[si] - torch.from_numpy(z['gsample/' + k])).norm() / (len(si) ** 0.5)) / rms
         nerr = abs(float(gflat.double().norm()) - gn_ref) / gn_ref
         worst[k] = (err, nerr)
+    print(f'{dtype}: pred rel-L1 {relp:.3e} loss rel {lrel:.3e} dloss/dpred rel-L1 {reld:.3e}; worst gradients',
+          sorted(worst.items(), key=lambda kv: -kv[1][0])[:8])
+    for k, (err, nerr) in worst.items():
         if f32:
             assert err <= 2e-2 and nerr <= 5e-3, (k, err, nerr)
         else:
-            assert err <= (0.08 if k in names[-4:] else 0.5), (k, err)
-    print(f'{dtype}: pred rel-L1 {relp:.3e} loss rel {lrel:.3e} dloss/dpred rel-L1 {reld:.3e}; worst gradients',
-          sorted(worst.items(), key=lambda kv: -kv[1][0])[:4])
+            assert err <= (0.08 if k in names[-4:] else 0.4) and nerr <= 3e-2, (k, err, nerr)
     gn = float(z['grad_norm'])
-    assert abs(tr.state[3].item() - gn) <= (2e-3 if f32 else 5e-2) * gn
+    assert abs(tr.state[3].item() - gn) <= (2e-3 if f32 else 2e-2) * gn
     if f32:
         for k, prm in model.named_parameters():
             si = _sample_idx(prm.numel(), k)
             gs = torch.from_numpy(z['gsample/' + k]).abs()
             m = gs > 1e-2 * gs.max()                       # Adam's sign-like step is ill-conditioned where g ~ 0
             d = (prm.detach().cpu().reshape(-1)[si] - torch.from_numpy(z['p1sample/' + k])).abs()[m]
-            assert float(d.max()) <= 0.05 * lr, (k, float(d.max()) / lr)
+            assert float(d.max()) <= 0.1 * lr, (k, float(d.max()) / lr)
     sd = model.state_dict()
     for k in z.files:
         if not k.startswith('sd1/'):

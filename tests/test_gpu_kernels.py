@@ -297,7 +297,8 @@ def test_epilogue_z_stats_and_bn(dtype, shape):
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('shape', [(2, 128, 0, 64, 8), (2, 10, 0, 6, 4), (8, 128, 0, 64, 64), (16, 128, 0, 64, 64),
                                    (16, 128, 0, 128, 64),    # ring kernel: S2 BWD with two 128-channel segments, T2 BWD accumulating
-                                   (20, 128, 0, 64, 64)])    # ring kernel: the two segments inside ONE 128-column tile, 320 tiles
+                                   (20, 128, 0, 64, 64),     # ring kernel: the two segments inside ONE 128-column tile, 320 tiles
+                                   (32, 64, 0, 128, 64)])    # ring kernel: D1 dgrad of unet_256 at B = 32 (4 tiles per workgroup, 2 super-steps)
 def test_epilogue_bwd_two_segments(dtype, shape):
     """convT dgrad with ReLU mask, split into a skip segment (no stats) and an up segment (BN-bwd stats),
     then accumulate a second contribution with a LeakyReLU mask."""
