@@ -27,7 +27,7 @@ namespace {
 //                                               zero-record descriptor (every load dropped, zeros in LDS; wrong results)
 //   ADN_IGEMM_SKIP                              timing-only builds: bit 0 / 1 = the operand's LDS-DMA is not issued at all
 struct Tune {
-  int bm = 0, bn = 0, ns = 0, noa = 0, nob = 0, skip = 0, patch = 1, tall = 1, pair = 1, tinycap = 4, bn_t2 = 0, onepx = 1, nopre = 0, ring = 1, ring_sched = 1, ring_epi = 0, ring_geom = -1, ring_hs = 0;
+  int bm = 0, bn = 0, ns = 0, noa = 0, nob = 0, skip = 0, patch = 1, tall = 1, pair = 1, tinycap = 4, bn_t2 = 0, onepx = 1, nopre = 0, ring = 1, ring_sched = 1, ring_epi = 0, ring_geom = -1, ring_hs = 0, ring64n = 1;
 };
 const Tune& tune() {
   static Tune t;
@@ -50,7 +50,8 @@ const Tune& tune() {
     if (const char* e = getenv("ADN_IGEMM_RING_SCHED")) t.ring_sched = atoi(e);
     if (const char* e = getenv("ADN_IGEMM_RING_EPI")) t.ring_epi = atoi(e);      // A/B: ring kernel only for this epilogue (1 | 3)
     if (const char* e = getenv("ADN_IGEMM_RING_GEOM")) t.ring_geom = atoi(e);    // A/B: ring kernel only for this geometry (0 | 1)
-    if (const char* e = getenv("ADN_IGEMM_RING_HS")) t.ring_hs = atoi(e);        // A/B: ring kernel only at this small-grid height
+    if (const char* e = getenv("ADN_IGEMM_RING_HS")) t.ring_hs = atoi(e);
+    if (const char* e = getenv("ADN_IGEMM_RING_N64")) t.ring64n = atoi(e);       // A/B: 64-column layers on the ring kernel too        // A/B: ring kernel only at this small-grid height
   });
   return t;
 }
@@ -1092,11 +1093,12 @@ bool make_plan(const AdnIgemmDesc* d, Plan* pl) {
   // of partial rows -- depends on the epilogue: adn_igemm_num_partials must be asked with the epilogue of the launch.)
   pl->ring = false;
   if (d->dtype == ADN_BF16 && pl->wide && ns == 1 && !pl->pair && (d->geom == ADN_GEMM_S2 || d->geom == ADN_GEMM_T2) &&
-      d->Hs % 16 == 0 && d->Ws % 16 == 0 && d->N % 128 == 0 && (d->geom == ADN_GEMM_S2 || Cin % 128 == 0) && tn.ring != 0 &&
+      d->Hs % 16 == 0 && d->Ws % 16 == 0 && (d->N % 128 == 0 || (d->N == 64 && tn.ring64n != 0)) &&
+      (d->geom == ADN_GEMM_S2 || Cin % 128 == 0) && tn.ring != 0 && pl->mout * d->N < (1ll << 31) &&
       (d->epi == ADN_EPI_Z_STATS || d->epi == ADN_EPI_BWD) && (tn.ring_epi == 0 || tn.ring_epi == d->epi) &&
       (tn.ring_geom < 0 || tn.ring_geom == d->geom) && (tn.ring_hs == 0 || tn.ring_hs == d->Hs)) {
     const int64_t t128 = msmall / 256 * (d->N / 128) * pl->phases;
-    const int rbn = (tn.ring == 64 || (tn.ring != 128 && t128 < 192)) ? 64 : 128;    // too few 128-column tiles to fill the chip: 64
+    const int rbn = (d->N == 64 || tn.ring == 64 || (tn.ring != 128 && t128 < 192)) ? 64 : 128;    // too few 128-column tiles to fill the chip: 64
     pl->ring = true;
     pl->patch = pl->tall = false;
     pl->bm = 256;
@@ -1203,7 +1205,10 @@ void launch_ring1(const KParams& kp, const Plan& pl, hipStream_t st) {
   const int ntiles = pl.tiles_m * pl.tiles_n * pl.phases;
   const int cus = device_cus();
   const int nwgs = ntiles < cus ? ntiles : cus;
-  hipLaunchKernelGGL((igemm_ring_kernel<GEOM, BN, SCHED>), dim3(nwgs), dim3(512), lds, st, kp, ntiles, nwgs);
+  auto magic = [](int d) -> unsigned { return (unsigned)((1ull << 32) / (unsigned)d + 1ull); };     // x / d = mulhi(x, magic), x * d < 2^32
+  const int tpr = kp.Ws >> 4, tpi = (kp.Hs >> 4) * tpr;
+  hipLaunchKernelGGL((igemm_ring_kernel<GEOM, BN, SCHED>), dim3(nwgs), dim3(512), lds, st, kp, ntiles, nwgs,
+                     pl.tiles_n == 1 ? 0u : magic(pl.tiles_n), tpi == 1 ? 0u : magic(tpi), tpr == 1 ? 0u : magic(tpr));
 }
 template <int GEOM, int BN>
 void launch_ring2(const KParams& kp, const Plan& pl, hipStream_t st) {

@@ -61,7 +61,8 @@ struct RingTile {
 };
 
 template <int GEOM, int BN, int SCHED>
-__global__ __launch_bounds__(512, 2) void igemm_ring_kernel(KParams p, int ntiles, int nwgs) {
+__global__ __launch_bounds__(512, 2) void igemm_ring_kernel(KParams p, int ntiles, int nwgs, unsigned mg_tn, unsigned mg_tpi,
+                                                             unsigned mg_tpr) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr bool S2 = GEOM == ADN_GEMM_S2;
   constexpr int MW = 17, PLANE = 17 * 17;
@@ -97,16 +98,21 @@ __global__ __launch_bounds__(512, 2) void igemm_ring_kernel(KParams p, int ntile
   const int tpr = Ws >> 4, tpi = (Hs >> 4) * tpr;   // 16 x 16 tiles per image row / per image
   if (my_tiles <= 0) return;
 
+  // tile id -> (column tile, phase, image, pixel tile): divisions by launch constants as multiply-high with host-made
+  // reciprocals (floor(2^32 / d) + 1: exact for x * d < 2^32, tile ids are < 2^20) -- the three request cursors and the
+  // epilogue decode a tile each, a hardware-less integer division is ~25 instructions
+  auto fdiv = [](int x, unsigned magic, int d) -> int { return d == 1 ? x : (int)__umulhi((unsigned)x, magic); };
   auto decode_tile = [&](int k, RingTile& t) {
     const int id = wgx + k * nwgs;
-    t.tile_n = id % p.tiles_n;
-    const int r = id / p.tiles_n;
+    const int r = fdiv(id, mg_tn, p.tiles_n);
+    t.tile_n = id - r * p.tiles_n;
     t.phase = r % NPH;
     t.tile_m = r / NPH;
-    t.tb = t.tile_m / tpi;
+    t.tb = fdiv(t.tile_m, mg_tpi, tpi);
     const int rem = t.tile_m - t.tb * tpi;
-    t.oy0 = (rem / tpr) << 4;
-    t.ox0 = (rem % tpr) << 4;
+    const int ry = fdiv(rem, mg_tpr, tpr);
+    t.oy0 = ry << 4;
+    t.ox0 = (rem - ry * tpr) << 4;
   };
 
   typedef __attribute__((address_space(3))) void* lptr_t;
@@ -115,41 +121,63 @@ __global__ __launch_bounds__(512, 2) void igemm_ring_kernel(KParams p, int ntile
   const char* gbase1 = reinterpret_cast<const char*>(p.C1 ? p.in1 : p.in0) - (int64_t)bshift * p.C1 * 2;
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.rec_b, 0x00020000);
 
-  // ---- per-lane constants of the patch loader: piece pi covers LDS pixels 16 pi .. 16 pi + 15 ----
-  // piece of (wave, k): wave + 8k; T2 has 20 pieces: k = 2 of waves 4..7 repeats pieces 16..19 (same bytes to the same
-  // LDS address) so that every wave issues the same number of requests -- the vmcnt counts below are per wave
+  // ---- per-lane constants (patch / weight loader offsets, fragment base addresses) ----
+  // ~40 registers that are dead during the epilogue: they are RE-COMPUTED after every epilogue from an opaque copy of the
+  // lane id (so that the compiler cannot keep the first computation alive instead), which is what lets the BWD epilogue
+  // keep its operand loads in flight without spilling
   auto piece_of = [&](int k) -> int { return (!S2 && k == 2) ? 16 + (wave & 3) : wave + 8 * k; };
   unsigned prel[PKW];          // pixel offset of this lane's pixel relative to the tile's patch origin
   unsigned phm[PKW];           // hr | m << 8 | column parity << 16 | (pixel beyond the segment) << 24
+  unsigned lc16;               // source-side chunk swizzle of the patch pieces: (q >> 2) & 1 = (lane >> 4) & 1
+  unsigned bvo[WPW];           // weight loader: piece pid = wave + 8k of a step's [2][BN][64 B] tile
+  unsigned pa[4][4], wa[NT];   // fragment base addresses (see below)
+  auto lane_consts = [&]() {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int l_frow = ln & 15, l_fq = ln >> 4;
 #pragma unroll
-  for (int k = 0; k < PKW; ++k) {
-    const int q = 16 * piece_of(k) + (lane >> 2);
-    int cpar = 0, rem = q;
-    if constexpr (S2) {
-      cpar = q >= PLANE ? 1 : 0;
-      rem = q - cpar * PLANE;
+    for (int k = 0; k < PKW; ++k) {
+      const int q = 16 * piece_of(k) + (ln >> 2);
+      int cpar = 0, rem = q;
+      if constexpr (S2) {
+        cpar = q >= PLANE ? 1 : 0;
+        rem = q - cpar * PLANE;
+      }
+      const int hr = rem / MW, m = rem - hr * MW;
+      const bool beyond = q >= SEG_PIX;
+      phm[k] = (unsigned)hr | ((unsigned)m << 8) | ((unsigned)cpar << 16) | (beyond ? 1u << 24 : 0u);
+      prel[k] = S2 ? (unsigned)(2 * hr * Wg + 2 * m + cpar) : (unsigned)(hr * Wg + m);
     }
-    const int hr = rem / MW, m = rem - hr * MW;
-    const bool beyond = q >= SEG_PIX;
-    phm[k] = (unsigned)hr | ((unsigned)m << 8) | ((unsigned)cpar << 16) | (beyond ? 1u << 24 : 0u);
-    prel[k] = S2 ? (unsigned)(2 * hr * Wg + 2 * m + cpar) : (unsigned)(hr * Wg + m);
-  }
-  const unsigned lc16 = (unsigned)(((lane & 3) ^ (((lane >> 4) & 1) << 1)) << 4);   // source-side chunk swizzle (q>>2)&1 = (lane>>4)&1
-  // ---- per-lane constants of the weight loader: piece pid = wave + 8k of a step's [2][BN][64 B] tile ----
-  // LDS row L of a tap holds output channel chan(L): inside a wave's BN/2 rows, MFMA tile j (L >> 4) row rho (L & 15) is
-  // channel (j >> 1) * 32 + (rho >> 2) * 8 + (j & 1) * 4 + (rho & 3), so that a lane's accumulators of tiles 2h, 2h + 1 are
-  // the 8 CONSECUTIVE channels h * 32 + fq * 8 .. + 7 of its pixel: 16-byte epilogue accesses, 64 contiguous bytes per pixel
-  // and wave-instruction
-  unsigned bvo[WPW];
+    lc16 = (unsigned)(((ln & 3) ^ (((ln >> 4) & 1) << 1)) << 4);
+    // LDS row L of a tap holds output channel chan(L): inside a wave's BN/2 rows, MFMA tile j (L >> 4) row rho (L & 15) is
+    // channel (j >> 1) * 32 + (rho >> 2) * 8 + (j & 1) * 4 + (rho & 3), so that a lane's accumulators of tiles 2h, 2h + 1 are
+    // the 8 CONSECUTIVE channels h * 32 + fq * 8 .. + 7 of its pixel: 16-byte epilogue accesses, 64 contiguous bytes per
+    // pixel and wave-instruction
 #pragma unroll
-  for (int k = 0; k < WPW; ++k) {
-    const int pid = wave + 8 * k;
-    const int tsel = pid / (BN / 16), row = (pid % (BN / 16)) * 16 + (lane >> 2);
-    const int l = row % (BN / 2), j = l >> 4, rho = l & 15;
-    const int chan = (row - l) + (j >> 1) * 32 + (rho >> 2) * 8 + (j & 1) * 4 + (rho & 3);
-    const int lc = (lane & 3) ^ (((row >> 2) & 1) << 1);
-    bvo[k] = (unsigned)((chan * ktot + tsel * Cin + lc * 8) * 2);
-  }
+    for (int k = 0; k < WPW; ++k) {
+      const int pid = wave + 8 * k;
+      const int tsel = pid / (BN / 16), row = (pid % (BN / 16)) * 16 + (ln >> 2);
+      const int l = row % (BN / 2), j = l >> 4, rho = l & 15;
+      const int chan = (row - l) + (j >> 1) * 32 + (rho >> 2) * 8 + (j & 1) * 4 + (rho & 3);
+      const int lc = (ln & 3) ^ (((row >> 2) & 1) << 1);
+      bvo[k] = (unsigned)((chan * ktot + tsel * Cin + lc * 8) * 2);
+    }
+    // pixel fragment of pixel-row i at tap offset qoff: LDS pixel q = q0[i] + qoff, chunk fq ^ (((q >> 2) & 1) << 1); the
+    // swizzle bit only depends on qoff & 7 (adding a multiple of 8 pixels keeps bit 2), and the tap offsets of both
+    // geometries have qoff & 7 in {0, 1, 2, 3}: four base registers per pixel-row, everything else is an immediate
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q0 = (wm * 4 + i) * MW + l_frow;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) pa[i][c] = (unsigned)(q0 * 64 + ((l_fq ^ ((((q0 + c) >> 2) & 1) << 1)) << 4));
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int row = wn * (BN / 2) + j * 16 + l_frow;
+      wa[j] = (unsigned)(W_OFF + row * 64 + ((l_fq ^ (((row >> 2) & 1) << 1)) << 4));
+    }
+  };
+  lane_consts();
 
   // ---- request cursors (wave-uniform scalars); a dead cursor keeps issuing out-of-range requests (zeros into slots nobody
   // reads any more) so that the request count per K-step never changes ----
@@ -243,23 +271,6 @@ __global__ __launch_bounds__(512, 2) void igemm_ring_kernel(KParams p, int ntile
     }
   };
 
-  // ---- fragment addresses: per-lane base registers, everything else is an immediate ----
-  // pixel fragment of pixel-row i at tap offset qoff: LDS pixel q = q0[i] + qoff, chunk fq ^ (((q >> 2) & 1) << 1); the swizzle
-  // bit only depends on qoff & 7 (adding a multiple of 8 pixels keeps bit 2), and the tap offsets of both geometries have
-  // qoff & 7 in {0, 1, 2, 3}: four base registers per pixel-row
-  unsigned pa[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int q0 = (wm * 4 + i) * MW + frow;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) pa[i][c] = (unsigned)(q0 * 64 + ((fq ^ ((((q0 + c) >> 2) & 1) << 1)) << 4));
-  }
-  unsigned wa[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int row = wn * (BN / 2) + j * 16 + frow;
-    wa[j] = (unsigned)(W_OFF + row * 64 + ((fq ^ (((row >> 2) & 1) << 1)) << 4));
-  }
   // tap offset (LDS pixels) of tap e of step-in-segment ss
   auto qoff_of = [](int ss, int e) constexpr -> int {
     return S2 ? ((e * 17) + (ss >> 1)) * MW + (ss & 1) : (ss == 0 ? 1 : 0) * MW + (e == 0 ? 1 : 0);
@@ -297,7 +308,18 @@ __global__ __launch_bounds__(512, 2) void igemm_ring_kernel(KParams p, int ntile
   // ---- epilogue straight from the accumulators ----
   // acc[i][2h + b][r] = pixel (tile row wm*4 + i, column frow), channel n0 + 32 h + 8 fq + 4 b + r
   float* red = reinterpret_cast<float*>(smem + R_OFF);      // [8 waves][2][BN/2]
-  auto epilogue = [&](int k) {
+#ifdef ADN_RING_STAMPS
+  unsigned long long sum_ea = 0, sum_eb = 0, sum_ec = 0, sum_ed = 0;
+#endif
+  // The data-dependent options (bias, accumulate, BatchNorm sums) are compile-time flags of the body: tested per element
+  // they became a branch around every single load, and the loads of an absent bias made the Z_STATS path wait vmcnt(0)
+  // -- i.e. for the whole staging ring -- before its first store.
+  auto epilogue_body = [&](int k, auto BWD_, auto FLAG_A, auto FLAG_S) {
+    constexpr bool BWD = decltype(BWD_)::value;
+    constexpr bool FA = decltype(FLAG_A)::value;       // Z_STATS: the conv has a bias;  BWD: accumulate into the output
+    constexpr bool STATS = decltype(FLAG_S)::value;    // this wave's segment takes BatchNorm sums
+    [[maybe_unused]] unsigned long long x0, x1, x2, x3, x4;
+    RING_STAMP(x0);
     RingTile t;
     decode_tile(k, t);
     const int n0 = t.tile_n * BN + wn * (BN / 2);             // first channel of this wave (wave-uniform)
@@ -305,13 +327,12 @@ __global__ __launch_bounds__(512, 2) void igemm_ring_kernel(KParams p, int ntile
     const AdnEpiSeg& sg = first ? p.seg[0] : p.seg[1];
     const int nl0 = (first ? n0 : n0 - p.seg[0].channels) + 8 * fq;
     const int ph = t.phase >> 1, pw = t.phase & 1;
-    int64_t opix[4];
+    unsigned opix[4];            // element offsets (validate() bounds every tensor of the launch by 2^31 elements)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int oy = t.oy0 + wm * 4 + i, ox = t.ox0 + frow;
-      opix[i] = (S2 ? ((int64_t)t.tb * Hs + oy) * Ws + ox : ((int64_t)t.tb * Hl + 2 * oy + ph) * Wl + 2 * ox + pw) * sg.channels + nl0;
+      opix[i] = (unsigned)(S2 ? (t.tb * Hs + oy) * Ws + ox : (t.tb * Hl + 2 * oy + ph) * Wl + 2 * ox + pw) * (unsigned)sg.channels + (unsigned)nl0;
     }
-    const bool stats = sg.partials != nullptr;
     const bool any_stats = p.seg[0].partials != nullptr || p.seg[1].partials != nullptr;     // workgroup-uniform
     uint16_t* out = reinterpret_cast<uint16_t*>(sg.out0);
     float s1[NH][8], s2[NH][8];
@@ -328,27 +349,39 @@ __global__ __launch_bounds__(512, 2) void igemm_ring_kernel(KParams p, int ntile
       }
       return pk;
     };
-    if (p.epi == ADN_EPI_Z_STATS) {
+    if constexpr (!BWD) {
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
         float bias[8];
+        if constexpr (FA) {
+          const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(sg.bias + nl0 + 32 * h);
+          const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(sg.bias + nl0 + 32 * h + 4);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bias[e] = sg.bias ? sg.bias[nl0 + 32 * h + e] : 0.f;
+          for (int e = 0; e < 4; ++e) {
+            bias[e] = b0[e];
+            bias[4 + e] = b1[e];
+          }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            const float v = acc[i][2 * h + (e >> 2)][e & 3] + bias[e];
-            acc[i][2 * h + (e >> 2)][e & 3] = v;
-            s1[h][e] += v;
-            s2[h][e] += v * v;
+            float v = acc[i][2 * h + (e >> 2)][e & 3];
+            if constexpr (FA) {
+              v += bias[e];
+              acc[i][2 * h + (e >> 2)][e & 3] = v;
+            }
+            if constexpr (STATS) {
+              s1[h][e] += v;
+              s2[h][e] += v * v;
+            }
           }
           *reinterpret_cast<u32x4_t*>(out + opix[i] + 32 * h) = pack8(i, h);
         }
       }
-    } else {   // ADN_EPI_BWD: one pixel-row at a time, the next row's operands requested before this one is worked on; the
-               // outputs are stored after the LAST operand load (vmcnt retires in issue order: a store between two loads
-               // would put its write latency in front of the next load's data)
+    } else {   // BWD: one pixel-row at a time, the next row's operands requested before this one is worked on; the outputs
+               // are stored after the LAST operand load (vmcnt retires in issue order: a store between two loads would
+               // put its write latency in front of the next load's data)
       const uint16_t* ref = reinterpret_cast<const uint16_t*>(sg.ref);
       const uint16_t* zz = reinterpret_cast<const uint16_t*>(sg.z);
       const float slope = sg.slope;
@@ -356,12 +389,10 @@ __global__ __launch_bounds__(512, 2) void igemm_ring_kernel(KParams p, int ntile
       auto request = [&](int i, u32x4_t* r_, u32x4_t* o_, u32x4_t* z_) {
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
-          const int64_t idx = opix[i] + 32 * h;
+          const unsigned idx = opix[i] + 32 * h;
           r_[h] = *reinterpret_cast<const u32x4_t*>(ref + idx);
-          o_[h] = u32x4_t{0u, 0u, 0u, 0u};
-          z_[h] = u32x4_t{0u, 0u, 0u, 0u};
-          if (sg.accumulate) o_[h] = *reinterpret_cast<const u32x4_t*>(out + idx);
-          if (stats) z_[h] = *reinterpret_cast<const u32x4_t*>(zz + idx);
+          if constexpr (FA) o_[h] = *reinterpret_cast<const u32x4_t*>(out + idx);
+          if constexpr (STATS) z_[h] = *reinterpret_cast<const u32x4_t*>(zz + idx);
         }
       };
       request(0, rr[0], oo[0], zr[0]);
@@ -375,8 +406,8 @@ __global__ __launch_bounds__(512, 2) void igemm_ring_kernel(KParams p, int ntile
             const uint32_t sh = (e & 1) ? 0u : 16u;
             const float rf = __uint_as_float((rr[i & 1][h][e >> 1] << sh) & 0xffff0000u);
             float g = acc[i][2 * h + (e >> 2)][e & 3] * (rf > 0.f ? 1.0f : slope);
-            if (sg.accumulate) g += __uint_as_float((oo[i & 1][h][e >> 1] << sh) & 0xffff0000u);
-            if (stats) {       // s2 = sum g * z here; (sum g z - mean sum g) * istd once per channel below
+            if constexpr (FA) g += __uint_as_float((oo[i & 1][h][e >> 1] << sh) & 0xffff0000u);
+            if constexpr (STATS) {       // s2 = sum g * z here; (sum g z - mean sum g) * istd once per channel below
               s1[h][e] += g;
               s2[h][e] += g * __uint_as_float((zr[i & 1][h][e >> 1] << sh) & 0xffff0000u);
             }
@@ -388,19 +419,27 @@ __global__ __launch_bounds__(512, 2) void igemm_ring_kernel(KParams p, int ntile
 #pragma unroll
         for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4_t*>(out + opix[i] + 32 * h) = pack8(i, h);
     }
+    RING_STAMP(x1);
     // column sums: over the 16 pixels of a DPP row by rotations (every lane ends with the row total), then over the four
     // pixel-row waves that share these channels through LDS
     if (any_stats) {
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
+        if constexpr (STATS) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          s1[h][e] = ring_row_sum(s1[h][e]);
-          s2[h][e] = ring_row_sum(s2[h][e]);
-        }
-        if (p.epi == ADN_EPI_BWD && stats) {
+          for (int e = 0; e < 8; ++e) {
+            s1[h][e] = ring_row_sum(s1[h][e]);
+            s2[h][e] = ring_row_sum(s2[h][e]);
+          }
+          if constexpr (BWD) {
+            const f32x4_t m0 = *reinterpret_cast<const f32x4_t*>(sg.mean + nl0 + 32 * h), m1 = *reinterpret_cast<const f32x4_t*>(sg.mean + nl0 + 32 * h + 4);
+            const f32x4_t i0 = *reinterpret_cast<const f32x4_t*>(sg.istd + nl0 + 32 * h), i1 = *reinterpret_cast<const f32x4_t*>(sg.istd + nl0 + 32 * h + 4);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) s2[h][e] = (s2[h][e] - sg.mean[nl0 + 32 * h + e] * s1[h][e]) * sg.istd[nl0 + 32 * h + e];
+            for (int e = 0; e < 4; ++e) {
+              s2[h][e] = (s2[h][e] - m0[e] * s1[h][e]) * i0[e];
+              s2[h][4 + e] = (s2[h][4 + e] - m1[e] * s1[h][4 + e]) * i1[e];
+            }
+          }
         }
         if (frow == 0) {
           float* r1 = red + (wave * 2 + 0) * (BN / 2) + 32 * h + 8 * fq;
@@ -411,9 +450,11 @@ __global__ __launch_bounds__(512, 2) void igemm_ring_kernel(KParams p, int ntile
           *reinterpret_cast<f32x4_t*>(r2 + 4) = f32x4_t{s2[h][4], s2[h][5], s2[h][6], s2[h][7]};
         }
       }
+      RING_STAMP(x2);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (not __syncthreads(): its vmcnt(0) would drain the ring)
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      RING_STAMP(x3);
       if (tid < 2 * BN) {
         const int st = tid / BN, c = tid % BN;
         const int cw = c / (BN / 2), cc = c % (BN / 2);
@@ -425,6 +466,39 @@ __global__ __launch_bounds__(512, 2) void igemm_ring_kernel(KParams p, int ntile
         const int ncl = (n < p.seg[0].channels) ? n : n - p.seg[0].channels;
         const int64_t P = (int64_t)t.phase * p.tiles_m + t.tile_m;
         if (sq.partials) sq.partials[(P * 2 + st) * sq.channels + ncl] = tot;
+      }
+#ifdef ADN_RING_STAMPS
+      RING_STAMP(x4);
+      sum_ea += x1 - x0; sum_eb += x2 - x1; sum_ec += x3 - x2; sum_ed += x4 - x3;
+#endif
+    }
+  };
+  auto epilogue = [&](int k) {
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    // (wave-uniform dispatch: which segment this wave's channels belong to only depends on the tile and wn)
+    RingTile t;
+    decode_tile(k, t);
+    const int n0 = t.tile_n * BN + wn * (BN / 2);
+    const AdnEpiSeg& sg = n0 < p.seg[0].channels ? p.seg[0] : p.seg[1];
+    const bool stats = sg.partials != nullptr;
+    if (p.epi == ADN_EPI_Z_STATS) {
+      const bool bias = sg.bias != nullptr;
+      if (bias) {
+        if (stats) epilogue_body(k, F_{}, T_{}, T_{});
+        else epilogue_body(k, F_{}, T_{}, F_{});
+      } else {
+        if (stats) epilogue_body(k, F_{}, F_{}, T_{});
+        else epilogue_body(k, F_{}, F_{}, F_{});
+      }
+    } else {
+      const bool accu = sg.accumulate != 0;
+      if (accu) {
+        if (stats) epilogue_body(k, T_{}, T_{}, T_{});
+        else epilogue_body(k, T_{}, T_{}, F_{});
+      } else {
+        if (stats) epilogue_body(k, T_{}, F_{}, T_{});
+        else epilogue_body(k, T_{}, F_{}, F_{});
       }
     }
   };
@@ -451,6 +525,7 @@ __global__ __launch_bounds__(512, 2) void igemm_ring_kernel(KParams p, int ntile
 #ifdef ADN_RING_STAMPS
   unsigned long long sum_wait = 0, sum_issue = 0, sum_tap0 = 0, sum_tap1 = 0, sum_epi = 0, n_steps = 0, t_begin, t_end;
   RING_STAMP(t_begin);
+  const unsigned long long r_begin = __builtin_amdgcn_s_memrealtime();      // 100 MHz: shader clock = cycles / ticks * 100 MHz
 #endif
   bool after_epi = false;       // the 4 * NH output stores of the epilogue are younger than the previous request group
   // one K-step at super-step position U
@@ -546,6 +621,7 @@ __global__ __launch_bounds__(512, 2) void igemm_ring_kernel(KParams p, int ntile
     sum_epi += e1 - e0;
 #endif
     zero_acc();
+    lane_consts();
     // (re-read instead of keeping step 7's prefetch alive across the epilogue: 32 registers the epilogue needs)
     load_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, pfA, wfA);
     after_epi = true;
@@ -554,8 +630,10 @@ __global__ __launch_bounds__(512, 2) void igemm_ring_kernel(KParams p, int ntile
 #ifdef ADN_RING_STAMPS
   RING_STAMP(t_end);
   if (lane == 0 && p.slab != nullptr) {
-    unsigned long long* o = reinterpret_cast<unsigned long long*>(p.slab) + ((size_t)wgx * 8 + wave) * 8;
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(p.slab) + ((size_t)wgx * 8 + wave) * 16;
     o[0] = sum_wait; o[1] = sum_issue; o[2] = sum_tap0; o[3] = sum_tap1; o[4] = sum_epi; o[5] = n_steps; o[6] = t_end - t_begin; o[7] = my_tiles;
+    o[8] = __builtin_amdgcn_s_memrealtime() - r_begin;
+    o[9] = sum_ea; o[10] = sum_eb; o[11] = sum_ec; o[12] = sum_ed;
   }
 #endif
 #endif

@@ -19,6 +19,7 @@
 #include <stdlib.h>
 
 #include <mutex>
+#include <type_traits>
 
 #include "adn_common.h"
 
@@ -207,6 +208,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_s1_patch_kernel(SParams p) {
 // are 4 consecutive LDS rows for every tap.  Granule (16 channels) ^= parity of the plane row: a half wave reads 4 rows
 // of plane row h and 4 of plane row h + 1 -> conflict free.  Wave w: channels 16 (w & 1) .. + 15, kernel rows
 // ky = 2 (w >> 1), 2 (w >> 1) + 1, all kx: 8 taps x 4 row tiles = 32 accumulator tiles.
+constexpr unsigned OOB_K4 = 0x80000000u;
+
+// One LDS-DMA request (1 KiB per wave) as inline assembly.  Why not __builtin_amdgcn_raw_ptr_buffer_load_lds here: once the
+// fragment reads of the K loop are "base register + immediate" the compiler sees that the DMA and the ds_read_b64_tr_b16
+// builtins touch the same LDS array and orders EVERY read behind the youngest request with s_waitcnt vmcnt(0) -- the next
+// tile's staging would run in series with this tile's MFMAs.  The barrier protocol (vmcnt(0) + s_barrier per tile, two
+// buffers) already orders them; hidden in assembly the request is outside the compiler's bookkeeping, counted by hand.
+// M0 = LDS destination of the wave (written in the same statement that uses it, cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void k4_dma(unsigned voffset, u32x4_t rsrc, unsigned lds_addr, int soffset) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
+               :
+               : "v"(voffset), "s"(rsrc), "s"(lds_addr), "s"(soffset)
+               : "memory");
+}
+
 struct KParams4 {
   const void* plain0;
   const void* plain1;
@@ -220,13 +236,17 @@ struct KParams4 {
   int64_t out_elems;
 };
 
+// SPREAD: the next tile's LDS-DMA requests are issued BETWEEN the MFMAs of the current tile (two straight-line regions pinned
+// with sched_group_barrier) instead of in a burst behind the barrier: a request costs the issuing wave ~100 cycles, which the
+// other waves of the SIMD fill with their MFMAs (round 3; the same change was worth 8 ... 20 % in the implicit GEMM)
+template <bool SPREAD>
 __global__ __launch_bounds__(256, 2) void wgrad_k4_patch_kernel(KParams4 p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int TH = 8, TW = 8, PW = 9, PLANE = PW * PW, PPIX = 4 * PLANE;       // 324 patch pixels of 64 bytes
   constexpr int DZBUF = 64 * 128;
   constexpr int PPIECES = (PPIX * 64 + 1023) / 1024;                             // 21 (16 pixels each)
-  constexpr int PBUF = PPIECES * 1024;
   constexpr int PK = (PPIECES + 3) / 4;                                          // 6 per wave
+  constexpr int PBUF = 4 * PK * 1024;                                            // (24 pieces: every wave issues PK requests)
   constexpr unsigned OOB = 0x80000000u;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* DZl = smem;                    // [2][DZBUF]
@@ -280,11 +300,25 @@ __global__ __launch_bounds__(256, 2) void wgrad_k4_patch_kernel(KParams4 p) {
   const __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(reinterpret_cast<const char*>(gsecond ? p.gath1 : p.gath0) - (int64_t)bshift * Cs * 2), 0, 0x7ffffff0, 0x00020000);
 
+  // the same descriptors as plain SGPR quadruples for the inline-assembly requests (see k4_dma)
+  auto desc_of = [](const void* ptr) -> u32x4_t {
+    const unsigned long long a = (unsigned long long)ptr;
+    return u32x4_t{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, 0x7ffffff0u, 0x00020000u};
+  };
+  const u32x4_t dsd = desc_of(psecond ? p.plain1 : p.plain0);
+  const u32x4_t dsp = desc_of(reinterpret_cast<const char*>(gsecond ? p.gath1 : p.gath0) - (int64_t)bshift * Cs * 2);
   int tb = t_begin / p.tpi;
   int trem = t_begin - tb * p.tpi;
   int ty = trem / p.tpr, tx = trem - ty * p.tpr;
 
-  auto issue = [&](int buf) {
+  // requests K0 .. K1-1 of the tile at (tb, ty, tx) into buffer `buf` (index 0, 1 = the plain operand, 2 .. = patch pieces);
+  // straight-line: the pieces beyond the patch (wave + 4k >= 21) are issued out of range (zeros into the 3 padding KiB)
+  auto issue = [&](int buf, auto K0, auto K1, bool live) {
+    constexpr int k0 = decltype(K0)::value, k1 = decltype(K1)::value;
+    // (opaque buffer index: with a compile-time destination the compiler orders every later LDS read of the kernel behind the
+    //  request with s_waitcnt vmcnt(0) -- it cannot know that the barrier protocol keeps the two buffers apart)
+    asm volatile("" : "+s"(buf));
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const int oy0 = ty * TH, ox0 = tx * TW;
     const unsigned edge = (oy0 == 0 ? 1u : 0u) | (oy0 + TH == Hs ? 2u : 0u) | (ox0 == 0 ? 4u : 0u) | (ox0 + TW == Ws ? 8u : 0u) | 16u;
     char* dd = DZl + buf * DZBUF + wave * 1024;
@@ -292,12 +326,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_k4_patch_kernel(KParams4 p) {
     const int dso = ((tb * Hs + oy0) * Ws + ox0) * Rs * 2;
     const int pso = ((tb * Hl + 2 * oy0) * Wl + 2 * ox0) * Cs * 2;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (lptr_t)(dd + k * 4096), 16, dvo[k], dso, 0, 0);
-#pragma unroll
-    for (int k = 0; k < PK; ++k) {
-      if (wave + 4 * k >= PPIECES) continue;
-      const bool inval = ((pmask >> (5 * k)) & edge) != 0;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsp, (lptr_t)(pd + k * 4096), 16, inval ? OOB : pvo[k], pso, 0, 0);
+    for (int k = k0; k < k1; ++k) {
+      if (k < 2) {
+        k4_dma(live ? dvo[k] : OOB_K4, dsd, lds0 + (unsigned)(dd - smem) + k * 4096, dso);
+      } else {
+        const int kk = k - 2;
+        const bool inval = !live || ((pmask >> (5 * kk)) & edge) != 0;
+        k4_dma(inval ? OOB_K4 : pvo[kk], dsp, lds0 + (unsigned)(pd - smem) + kk * 4096, pso);
+      }
     }
   };
   auto advance = [&]() {
@@ -326,43 +362,78 @@ __global__ __launch_bounds__(256, 2) void wgrad_k4_patch_kernel(KParams4 p) {
     return *reinterpret_cast<bf16x8_t*>(&v);
   };
 
-  if (t_begin < t_end) issue(0);
-  for (int t = t_begin; t < t_end; ++t) {
-    const int cur = (t - t_begin) & 1;
+  // ---- fragment addresses: per-lane base registers + immediates (round 3) ----
+  // Round 2 recomputed every swizzled address per K-step (an opaque copy of the row stopped the compiler from hoisting all 48
+  // of them into registers): ~6 VALU instructions per MFMA, the kernel was VALU-issue bound.  Both swizzles only depend on
+  // bits the K-step does not touch, so one base per plain fragment column (4) and ONE for the patch suffice; the buffer
+  // (tile parity), the K-step, the tap's plane / row / column are immediates of the transposed reads.
+  unsigned abase[4];
+  {
+    const int m0 = 8 * fg + qq;                     // plain tile row of the low half at K-step 0 (the high half is + 4 rows)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) abase[i] = (unsigned)(m0 * 128 + ((i ^ swz4(m0)) << 5) + pp * 8);
+  }
+  const int kyh = wky >> 1;                         // (ky >> 1) is the same for both kernel rows of this wave
+  const unsigned pbase = (unsigned)(2 * DZBUF + ((fg + kyh) * PW + qq) * 64 + ((wct ^ ((fg + kyh) & 1)) << 5) + pp * 8);
+
+  using I0 = std::integral_constant<int, 0>;
+  using I4 = std::integral_constant<int, 4>;
+  using I8 = std::integral_constant<int, 2 + PK>;
+  // one pixel tile out of buffer CUR; the next tile's requests go into buffer CUR ^ 1
+  auto tile_body = [&](auto CUR, bool more) {
+    constexpr int cur = decltype(CUR)::value;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (t + 1 < t_end) {
-      advance();
-      issue(cur ^ 1);
+    if (more) advance();
+    if constexpr (!SPREAD) {
+      if (more) issue(cur ^ 1, I0{}, I8{}, true);
     }
-    const char* Db = DZl + cur * DZBUF;
-    const char* Pb = Pl + cur * PBUF;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      int mrow = 32 * ks + 8 * fg + qq;              // plain tile row of this lane's low half: pixel (4 ks + fg, qq)
-      int oyl = 4 * ks + fg;
-      asm volatile("" : "+v"(mrow), "+v"(oyl));      // opaque per K-step: no hoisting of the swizzled addresses
       bf16x8_t af[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        af[i] = tr_pair(Db + mrow * 128 + ((i ^ swz4(mrow)) << 5) + pp * 8, Db + (mrow + 4) * 128 + ((i ^ swz4(mrow + 4)) << 5) + pp * 8);
+      for (int i = 0; i < 4; ++i) {
+        const char* a = smem + abase[i] + (cur * DZBUF + ks * 32 * 128);
+        af[i] = tr_pair(a, a + 4 * 128);
+      }
+      auto read_tap = [&](int tl) -> bf16x8_t {
+        const int dky = tl >> 2, kx = tl & 3;          // ky = wky + dky
+        const int imm = cur * PBUF + ((((dky << 1) | (kx & 1)) * PLANE + 4 * ks * PW + (kx >> 1)) * 64);
+        const char* a = smem + pbase + imm;
+        return tr_pair(a, a + 4 * 64);
+      };
+      // the tap fragments one tap ahead of the MFMAs; one request of the next tile behind every second tap (the inline
+      // assembly keeps its place in the instruction stream: that IS the interleave)
+      bf16x8_t bq[2];
+      bq[0] = read_tap(0);
 #pragma unroll
       for (int tl = 0; tl < 8; ++tl) {
-        const int dky = tl >> 2, kx = tl & 3;          // ky = wky + dky
-        const int kyh = (wky >> 1);                    // (ky >> 1) is the same for both kernel rows of this wave
-        const int hrow = oyl + kyh;                    // plane row
-        const int row = ((dky << 1) | (kx & 1)) * PLANE + hrow * PW + qq + (kx >> 1);
-        const char* a = Pb + row * 64 + ((wct ^ (hrow & 1)) << 5) + pp * 8;
-        const bf16x8_t bfr = tr_pair(a, a + 4 * 64);
+        if (tl + 1 < 8) bq[(tl + 1) & 1] = read_tap(tl + 1);
+        if constexpr (SPREAD) {
+          if (tl & 1) {
+            const int rq = 4 * ks + (tl >> 1);          // request 0 .. 7 of the next tile (2 plain + 6 patch pieces per wave)
+            switch (rq) {
+              case 0: issue(cur ^ 1, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, more); break;
+              case 1: issue(cur ^ 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, more); break;
+              case 2: issue(cur ^ 1, std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{}, more); break;
+              case 3: issue(cur ^ 1, std::integral_constant<int, 3>{}, std::integral_constant<int, 4>{}, more); break;
+              case 4: issue(cur ^ 1, std::integral_constant<int, 4>{}, std::integral_constant<int, 5>{}, more); break;
+              case 5: issue(cur ^ 1, std::integral_constant<int, 5>{}, std::integral_constant<int, 6>{}, more); break;
+              case 6: issue(cur ^ 1, std::integral_constant<int, 6>{}, std::integral_constant<int, 7>{}, more); break;
+              default: issue(cur ^ 1, std::integral_constant<int, 7>{}, std::integral_constant<int, 8>{}, more); break;
+            }
+          }
+        }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[tl][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr, acc[tl][i], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) acc[tl][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bq[tl & 1], acc[tl][i], 0, 0, 0);
       }
     }
-#pragma unroll
-    for (int tl = 0; tl < 8; ++tl)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(acc[tl][i]));
+  };
+  if (t_begin < t_end) issue(0, I0{}, I8{}, true);
+  for (int t = t_begin; t < t_end; t += 2) {
+    tile_body(std::integral_constant<int, 0>{}, t + 1 < t_end);
+    if (t + 1 < t_end) tile_body(std::integral_constant<int, 1>{}, t + 2 < t_end);
   }
 
   float* out = p.out + (int64_t)split * p.out_elems;
@@ -383,12 +454,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_k4_patch_kernel(KParams4 p) {
 // ADN_WGRAD_PATCH=0 switches the patch-staged kernels off; ADN_WGRAD_WGS = workgroups a launch aims at (default 512 = one
 // resident wave of 2 per CU; every workgroup writes its own f32 slab block, so the slab traffic is proportional to it).
 int g_wgs = 512;
+int g_spread = 0;      // ADN_WGRAD_SPREAD=1: the k4 patch kernel issues its requests between the MFMAs instead of in a burst
+                       // behind the barrier (measured: 5 ... 15 % slower here -- each request re-derives its border mask)
 bool patch_enabled() {
   static int on = 1;
   static std::once_flag once;
   std::call_once(once, [] {
     if (const char* e = getenv("ADN_WGRAD_PATCH")) on = atoi(e);
     if (const char* e = getenv("ADN_WGRAD_WGS")) g_wgs = atoi(e) > 0 ? atoi(e) : 512;
+    if (const char* e = getenv("ADN_WGRAD_SPREAD")) g_spread = atoi(e);
   });
   return on != 0;
 }
@@ -484,9 +558,14 @@ int adn_wgrad_k4p_launch(const AdnWgradDesc* d, int nsplit, int64_t out_elems, v
   p.tiles_total = d->B * p.tpi;
   p.out = nsplit > 1 ? reinterpret_cast<float*>(d->workspace) : d->dw;
   p.out_elems = out_elems;
-  constexpr int lds = 2 * (64 * 128 + 21 * 1024);
-  ADN_SET_LDS_ONCE(lds, &wgrad_k4_patch_kernel);
-  hipLaunchKernelGGL(wgrad_k4_patch_kernel, dim3(p.nrb * p.ncb * nsplit), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), p);
+  constexpr int lds = 2 * (64 * 128 + 24 * 1024);
+  if (g_spread) {
+    ADN_SET_LDS_ONCE(lds, &wgrad_k4_patch_kernel<true>);
+    hipLaunchKernelGGL(wgrad_k4_patch_kernel<true>, dim3(p.nrb * p.ncb * nsplit), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), p);
+  } else {
+    ADN_SET_LDS_ONCE(lds, &wgrad_k4_patch_kernel<false>);
+    hipLaunchKernelGGL(wgrad_k4_patch_kernel<false>, dim3(p.nrb * p.ncb * nsplit), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), p);
+  }
   ADN_CHECK_LAUNCH();
   return ADN_OK;
 }

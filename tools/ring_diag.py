@@ -15,7 +15,7 @@ import torch  # noqa: E402
 from audio_depth_estimation_amd import kernels as K  # noqa: E402
 
 DEV, T, B = 'cuda', torch.bfloat16, 32
-SHAPES = [('L1_fwd', 0, 64, 64, 0, 128), ('L2_fwd', 0, 32, 128, 0, 256), ('L3_fwd', 0, 16, 256, 0, 512),
+SHAPES = [('D1_fwd', 1, 64, 128, 128, 64), ('L1_fwd', 0, 64, 64, 0, 128), ('L2_fwd', 0, 32, 128, 0, 256), ('L3_fwd', 0, 16, 256, 0, 512),
           ('D2_fwd', 1, 32, 256, 256, 128), ('D3_fwd', 1, 16, 512, 512, 256), ('D2_dgrad', 0, 32, 128, 0, 512)]
 
 
@@ -30,12 +30,12 @@ def main():
         hout = Hs if geom == 0 else 2 * Hs
         out = torch.empty(B, hout, hout, N, device=DEV, dtype=T)
         P, _ = K.igemm_query(T, geom, B, Hs, Hs, C0, C1, N, [N])
-        ws = torch.zeros(256 * 8 * 8 * 2, device=DEV)                 # 256 workgroups x 8 waves x 8 u64
+        ws = torch.zeros(256 * 8 * 16 * 2, device=DEV)                # 256 workgroups x 8 waves x 16 u64
         part = torch.empty(P * 2 * N, device=DEV)
         for _ in range(3):
             K.igemm(T, geom, B, Hs, Hs, in0, in1, w, N, 1, [K.Seg(N, out0=out, partials=part)], ws)
         torch.cuda.synchronize()
-        r = ws.view(torch.int64).view(256, 8, 8).cpu().double()
+        r = ws.view(torch.int64).view(256, 8, 16).cpu().double()
         r = r[r[:, :, 5] > 0]
         if r.numel() == 0:
             print(name, 'no stamps (not the diagnostic build, or the ring kernel did not run)')
@@ -43,10 +43,11 @@ def main():
         n = r[:, 5]
         wait, issue, t0, t1 = [(r[:, i] / n).mean().item() for i in range(4)]
         epi = (r[:, 4] / r[:, 7]).mean().item()
+        ep = [(r[:, i] / r[:, 7]).mean().item() for i in (9, 10, 11, 12)]
         tot = r[:, 6].mean().item()
         steps = n.mean().item()
         print(f'{name:9s} steps/wave {steps:6.0f}  per step: wait+barrier {wait:7.0f}  issue {issue:6.0f}  tap0 {t0:6.0f}  tap1 {t1:6.0f}'
-              f'  = {wait + issue + t0 + t1:7.0f} cyc | epilogue/tile {epi:7.0f} | kernel {tot:9.0f} cyc ({tot / 100:.0f} ticks of 10 ns?)', flush=True)
+              f'  = {wait + issue + t0 + t1:7.0f} cyc | epilogue/tile {epi:7.0f} (stores {ep[0]:.0f} stats {ep[1]:.0f} barrier {ep[2]:.0f} final {ep[3]:.0f}) | kernel {tot:9.0f} cyc, clock {(r[:, 6] / r[:, 8]).mean().item() * 100:.0f} MHz', flush=True)
 
 
 if __name__ == '__main__':
