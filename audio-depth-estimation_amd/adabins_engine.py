@@ -423,12 +423,11 @@ class AdaBinsTrainer(GraphedStep):
         self._setup(device)
         if optim_state.is_torch_format(sd):
             step, group = optim_state.import_state(sd, self._optim_meta(), self.engine._view, self.exp_avg, self.exp_avg_sq)
+            optim_state.adopt_group(self, group)
             self.state[0] = float(step)
-            self.lr = float(group.get('lr', self.lr))
         elif 'exp_avg' in sd:
-            self.exp_avg.copy_(sd['exp_avg'])
-            self.exp_avg_sq.copy_(sd['exp_avg_sq'])
-            self.state[0] = float(sd['step'])
+            step = optim_state.import_legacy_flat(sd, self.engine.param_meta, self.exp_avg, self.exp_avg_sq)
+            self.state[0] = float(step)
 
     def step(self, audio, rgb, gt):
         """audio [B,2,H,W], rgb [B,3,H,W] or None, gt [B,1,H,W] -> (total loss 0-dim device tensor, terms f32[8]).

@@ -143,7 +143,7 @@ class BaseResidualTrainer(GraphedStep):
 
     def load_state_dict(self, sd, device):
         """Restore a torch.optim state dict (optim_state.py; the 'optimizer_state_dict' entry of the checkpoints written
-        by train_dc._run or by the reference's torch optimizer); round 1's flat layout is still read."""
+        by train_dc._run or by the reference's torch optimizer); round 1's flat layout is re-sliced per parameter or rejected."""
         from . import optim_state
         if not self.engine._bound():
             self.engine.bind_parameters()
@@ -151,12 +151,11 @@ class BaseResidualTrainer(GraphedStep):
         if optim_state.is_torch_format(sd):
             step, group = optim_state.import_state(sd, self.engine.param_meta, self.engine._view, self.exp_avg,
                                                    self.exp_avg_sq)
+            optim_state.adopt_group(self, group)
             self.state[0] = float(step)
-            self.lr = float(group.get('lr', self.lr))
         elif 'exp_avg' in sd:
-            self.exp_avg.copy_(sd['exp_avg'])
-            self.exp_avg_sq.copy_(sd['exp_avg_sq'])
-            self.state[0] = float(sd['step'])
+            step = optim_state.import_legacy_flat(sd, self.engine.param_meta, self.exp_avg, self.exp_avg_sq)
+            self.state[0] = float(step)
 
     def _setup_optimizer(self, dev):
         if getattr(self, '_opt_ready', False):
@@ -170,15 +169,25 @@ class BaseResidualTrainer(GraphedStep):
         """AdaptiveBaseResidualLoss.set_epoch (utils_base_residual_loss.py:210-229) result."""
         self.lambda_recon, self.lambda_base = lambda_recon, lambda_base
 
+    _SCRATCH = ('lstats', 'bstats', 'loss_ws', 'norm_ws', 'recon', 'terms', 'struct', 'gfinal', 'dbase', 'dres')
+
     def _setup(self, pred):
+        """Loss / gradient scratch of one batch shape.  Every shape keeps its own set for the trainer's lifetime: a captured
+        hipGraph holds raw pointers into the set it was captured with, and an eager step on another shape in between (a
+        ragged last batch) must not free or rebind those buffers (round-2 advisor finding)."""
         eng, dev = self.engine, pred.device
         f64, f32 = dict(dtype=torch.float64, device=dev), dict(dtype=torch.float32, device=dev)
         self._setup_optimizer(dev)
-        self.lstats, self.bstats = torch.zeros(4, **f64), torch.zeros(4, **f64)
-        self.loss_ws, self.norm_ws = torch.empty(4096 + 8, **f64), torch.empty(1024 + 8, **f64)
-        self.recon, self.terms = torch.zeros(1, **f32), torch.zeros(4, **f32)
-        self.struct, self.gfinal = torch.empty_like(pred), torch.empty_like(pred)
-        self.dbase, self.dres = torch.empty_like(pred), torch.empty_like(pred)
+        sets = self.__dict__.setdefault('_scratch_sets', {})
+        key = tuple(pred.shape)
+        if key not in sets:
+            sets[key] = dict(lstats=torch.zeros(4, **f64), bstats=torch.zeros(4, **f64),
+                             loss_ws=torch.empty(4096 + 8, **f64), norm_ws=torch.empty(1024 + 8, **f64),
+                             recon=torch.zeros(1, **f32), terms=torch.zeros(4, **f32),
+                             struct=torch.empty_like(pred), gfinal=torch.empty_like(pred),
+                             dbase=torch.empty_like(pred), dres=torch.empty_like(pred))
+        for name in self._SCRATCH:
+            setattr(self, name, sets[key][name])
         if self.ddp is not None and not self._ready:
             self.ddp.attach(eng)
         self._ready = True

@@ -23,11 +23,12 @@ namespace {
 
 // Tuning / diagnosis knobs, read from the environment ONCE (not per launch):
 //   ADN_IGEMM_BM / ADN_IGEMM_BN / ADN_IGEMM_NS  force the tile rows / columns, cap the split-K count
-//   ADN_IGEMM_NOA / ADN_IGEMM_NOB               timing-only builds: the gathered / weight operand is read through a
-//                                               zero-record descriptor (every load dropped, zeros in LDS; wrong results)
-//   ADN_IGEMM_SKIP                              timing-only builds: bit 0 / 1 = the operand's LDS-DMA is not issued at all
+//   ADN_IGEMM_NOA / ADN_IGEMM_NOB               timing-only builds (make FLAGS_igemm=-DADN_TIMING_KNOBS; NOT in the shipped
+//                                               library): the gathered / weight operand is read through a zero-record
+//                                               descriptor (every load dropped, zeros in LDS; wrong results)
+//   ADN_IGEMM_SKIP                              same builds: bit 0 / 1 = the operand's LDS-DMA is not issued at all
 struct Tune {
-  int bm = 0, bn = 0, ns = 0, noa = 0, nob = 0, skip = 0, patch = 1, tall = 1, pair = 1, tinycap = 4, bn_t2 = 0, onepx = 1, nopre = 0, ring = 1, ring_sched = 1, ring_epi = 0, ring_geom = -1, ring_hs = 0, ring64n = 1;
+  int bm = 0, bn = 0, ns = 0, noa = 0, nob = 0, skip = 0, patch = 1, tall = 1, pair = 1, tinycap = 4, bn_t2 = 0, onepx = 1, ring = 1, ring_sched = 1, ring_epi = 0, ring_geom = -1, ring_hs = 0, ring64n = 1;
 };
 const Tune& tune() {
   static Tune t;
@@ -36,15 +37,16 @@ const Tune& tune() {
     if (const char* e = getenv("ADN_IGEMM_BM")) t.bm = atoi(e);
     if (const char* e = getenv("ADN_IGEMM_BN")) t.bn = atoi(e);
     if (const char* e = getenv("ADN_IGEMM_NS")) t.ns = atoi(e);
+#ifdef ADN_TIMING_KNOBS      // timing-only builds (wrong results): never compiled into the shipped library
     if (const char* e = getenv("ADN_IGEMM_NOA")) t.noa = atoi(e);
     if (const char* e = getenv("ADN_IGEMM_NOB")) t.nob = atoi(e);
     if (const char* e = getenv("ADN_IGEMM_SKIP")) t.skip = atoi(e);
+#endif
     if (const char* e = getenv("ADN_IGEMM_PATCH")) t.patch = atoi(e);
     if (const char* e = getenv("ADN_IGEMM_TALL")) t.tall = atoi(e);
     if (const char* e = getenv("ADN_IGEMM_PAIR")) t.pair = atoi(e);
     if (const char* e = getenv("ADN_IGEMM_TINYCAP")) t.tinycap = atoi(e);
     if (const char* e = getenv("ADN_IGEMM_ONEPX")) t.onepx = atoi(e);
-    if (const char* e = getenv("ADN_IGEMM_NOPRE")) t.nopre = atoi(e);
     if (const char* e = getenv("ADN_IGEMM_BN_T2")) t.bn_t2 = atoi(e);
     if (const char* e = getenv("ADN_IGEMM_RING")) t.ring = atoi(e);
     if (const char* e = getenv("ADN_IGEMM_RING_SCHED")) t.ring_sched = atoi(e);
@@ -101,9 +103,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 //   256 x  64, 4x1 waves, 2 stages, 2 workgroups per CU        N = 64: every wave keeps a 64x64 sub-tile
 //   256 x 128, 4x2 waves, 3 stages, 1 workgroup per CU         long K: the DMA of steps s+1 and s+2 stays in
 //             flight across the per-step barrier (counted s_waitcnt vmcnt, raw s_barrier)
-// PRE = false: instantiation without the backward-epilogue prefetch registers (<= 96 VGPRs that are dead weight in every
-// forward and every split-K launch, where the prefetch is off at run time anyway: with them the kernel sits at ~250 of 256
-// VGPRs and the fragment reads of the K loop are issued just in time, see tools/isa_lds_waits.py)
+// (PRE = false, an instantiation without the backward-epilogue prefetch registers for forward / split-K launches, was timed
+//  in round 3 on the small-image layers: L5 / L6 / D5 forward 20.7 / 16.6 / 32.3 -> 19.9 / 15.7 / 31.4 us, the rest +-1 %:
+//  inside the noise, so the template parameter stays but only PRE = true is instantiated)
 template <typename T, int BM, int BN, int NWN, int GEOM, bool WIDE, bool PRE = true>
 __global__ __launch_bounds__(BM * NWN, 2) void igemm_mfma_kernel(KParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins exist only in the device pass; the host needs the stub only
@@ -1123,14 +1125,6 @@ int launch_mfma(const KParams& kp, const Plan& pl, hipStream_t st) {
   const int epil = BM_ * (BN + 4) * 4;
   const int lds = stage > epil ? stage : epil;
   dim3 grid(pl.tiles_m * pl.tiles_n * pl.phases, 1, pl.nsplit);
-  if constexpr (sizeof(T) == 2) {
-    // (prepared at the end of round 2, NOT yet run on a GPU: off unless ADN_IGEMM_NOPRE=1; 116 instead of 214 VGPRs)
-    if (!(kp.epi == ADN_EPI_BWD && pl.nsplit == 1) && tune().nopre != 0) {     // the prefetch would be off at run time anyway
-      ADN_SET_LDS_ONCE(lds, &igemm_mfma_kernel<T, BM_, BN, NWN, GEOM, WIDE, false>);
-      hipLaunchKernelGGL((igemm_mfma_kernel<T, BM_, BN, NWN, GEOM, WIDE, false>), grid, dim3(BM_ * NWN), lds, st, kp);
-      return 0;
-    }
-  }
   ADN_SET_LDS_ONCE(lds, &igemm_mfma_kernel<T, BM_, BN, NWN, GEOM, WIDE>);
   hipLaunchKernelGGL((igemm_mfma_kernel<T, BM_, BN, NWN, GEOM, WIDE>), grid, dim3(BM_ * NWN), lds, st, kp);
   return 0;

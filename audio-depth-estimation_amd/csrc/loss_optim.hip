@@ -88,11 +88,11 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const float* pred, con
     // an empty mask gives mean-of-empty = NaN in the reference (train.py:656); keep that signal
     loss_out[0] = N > 0.0 ? (float)(w1 * l1 + w2 * silog) : __int_as_float(0x7fc00000);
   }
-  if (!grad) return;
+  if (criterion != 4 && !grad) return;
   if (criterion == 4) {            // masked MSE (BaseResidualLoss use_l1 = False, utils_base_residual_loss.py:60-65)
     w1 = (double)l1w;
     w2 = 0.0;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && loss_out)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && loss_out)       // (also for a loss-only call: grad == nullptr)
       loss_out[0] = N > 0.0 ? (float)(w1 * stats[1] / N) : __int_as_float(0x7fc00000);
     if (!grad) return;
     const float c = N > 0.0 ? (float)(2.0 * w1 * (double)scale / N) : 0.f;

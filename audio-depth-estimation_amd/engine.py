@@ -555,6 +555,7 @@ class FusedTrainer:
         self.exp_avg = torch.zeros_like(eng.flat_p)
         self.exp_avg_sq = torch.zeros_like(eng.flat_p)
         self.gout = None
+        self._gout_sets = {}
         self._flat_id = eng.flat_p.data_ptr()
         if self.ddp is not None:
             self.ddp.attach(eng)
@@ -575,18 +576,18 @@ class FusedTrainer:
 
     def load_state_dict(self, sd, device):
         """Restore a ``torch.optim`` state dict (written by this class or by the reference's torch optimizer over the
-        same parameters); the flat layout of round 1 ('exp_avg' / 'exp_avg_sq' / 'step') is still read."""
+        same parameters); the flat layout of round 1 ('exp_avg' / 'exp_avg_sq' / 'step')
+        is re-sliced parameter by parameter (its alignment was 4 elements, today's is 8) or rejected."""
         from . import optim_state
         self._setup(device)
         if optim_state.is_torch_format(sd):
             step, group = optim_state.import_state(sd, self.engine.param_meta, self.engine._view, self.exp_avg,
                                                    self.exp_avg_sq)
+            optim_state.adopt_group(self, group)
             self._set_step(step)
-            self.lr = float(group.get('lr', self.lr))
         elif 'exp_avg' in sd:
-            self.exp_avg.copy_(sd['exp_avg'])
-            self.exp_avg_sq.copy_(sd['exp_avg_sq'])
-            self._set_step(int(sd['step']))
+            step = optim_state.import_legacy_flat(sd, self.engine.param_meta, self.exp_avg, self.exp_avg_sq)
+            self._set_step(step)
 
     def _set_step(self, step):
         """state = [step, 1 - beta1^step, 1 - beta2^step, ...] (adn_optimizer_step advances all three)."""
@@ -651,8 +652,12 @@ class FusedTrainer:
         pred = eng.forward(audio, True)
         gt = gt.contiguous().float()
         dz_ready = False
-        if self.gout is None or self.gout.shape != pred.shape:
-            self.gout = torch.empty_like(pred)
+        # loss-gradient scratch PER BATCH SHAPE, never freed: a captured hipGraph / launch plan holds its raw pointer, and an
+        # eager step on another batch shape in between (ragged last batch) must not hand that block back to the allocator
+        key = tuple(pred.shape)
+        if key not in self._gout_sets:
+            self._gout_sets[key] = torch.empty_like(pred)
+        self.gout = self._gout_sets[key]
         if self.criterion == 3:       # DepthLoss: unmasked L1 + total variation (train_rgb_depth.py:43-87)
             K.l1tv_stats(pred, gt, self.stats, self.loss_ws)
             if self.ddp is not None:

@@ -5,7 +5,8 @@ Same flags (:25-42), checkpoint resolution (--checkpoint_path | --experiment_nam
 per-sample ``compute_errors`` on metres (x max_depth when depth_norm, negatives clipped to 0), the seven mean
 metrics, and the stats dict saved under ./eval/<dataset>/<split>/stats_on_<dataset>_<split>_set_<exp>_epoch_<n>.pt.
 Forward pass, loss and metrics run on the device (one metrics kernel per batch instead of a numpy loop).
-PNG visualisation (--visualize) is reporting-only and not provided.  Extra flag: --synthetic N.
+PNG visualisation is reporting-only and not provided: --visualize / --vis_batch_size are accepted (the reference's command
+lines keep working) and a note is printed.  Extra flags: --synthetic N, --precision, --batch_size.
 """
 import argparse
 import os
@@ -27,7 +28,10 @@ def build_parser():
     p.add_argument('--checkpoint_path', type=str, default=None)
     p.add_argument('--checkpoints', type=int, default=50)
     p.add_argument('--eval_on', type=str, default='test', choices=['test', 'val'])
+    p.add_argument('--visualize', action='store_true', default=False,
+                   help='accepted for command-line compatibility (reference test.py:36); PNG panels are not produced')
     p.add_argument('--output_dir', type=str, default='./val/')
+    p.add_argument('--vis_batch_size', type=int, default=4, help='accepted and ignored (reference test.py:40)')
     p.add_argument('--precision', default='bf16', choices=['bf16', 'f32'])
     p.add_argument('--synthetic', type=int, default=0)
     p.add_argument('--batch_size', type=int, default=None)
@@ -55,6 +59,8 @@ def resolve_checkpoint(args, cfg):
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    if args.visualize:
+        print('--visualize: PNG panels are not produced by this build (metrics and the stats file are); flag ignored')
     cfg = load_config(dataset_name=args.dataset, mode='test', experiment_name=args.experiment_name or 'default')
     if args.checkpoints is not None:
         cfg.mode.checkpoints = args.checkpoints

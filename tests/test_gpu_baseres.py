@@ -132,6 +132,35 @@ def test_base_residual_trainer_resume_roundtrip():
         assert torch.equal(a, b), k
 
 
+def test_graph_step_survives_a_ragged_train_step():
+    """The trainer's loss / gradient scratch is kept per batch shape (round-2 advisor finding): a ragged trainer.step between
+    two replays of the captured step leaves the run bit-identical to the eager one."""
+    from audio_depth_estimation_amd.base_residual_engine import BaseResidualTrainer
+    from audio_depth_estimation_amd.models.base_residual_model import BaseResidualDepthNet
+    g = torch.Generator().manual_seed(10)
+    x = torch.rand(4, 2, 32, 32, generator=g).to('cuda')
+    gt = (30 * torch.rand(4, 1, 32, 32, generator=g)).to('cuda')
+    finals = []
+    for mode in ('eager', 'graph'):
+        torch.manual_seed(0)
+        m = BaseResidualDepthNet(2, 64, True, 32, 30.0)
+        m.compute_dtype = torch.bfloat16
+        m = m.to('cuda').train()
+        tr = BaseResidualTrainer(m.engine(), use_silog=True, lr=1e-3)
+        if mode == 'graph':
+            tr.enable_graph(after_steps=1)
+        for it in range(6):
+            tr.step(x, gt)
+            if it in (2, 4):
+                tr.step(x[:3], gt[:3])
+                junk = [torch.full((3, 1, 32, 32), float('nan'), device='cuda') for _ in range(8)]
+                del junk
+        torch.cuda.synchronize()
+        finals.append(m.engine().flat_p.detach().clone())
+    assert torch.isfinite(finals[1]).all()
+    assert torch.equal(finals[0], finals[1])
+
+
 def test_mse_reconstruction_variant_matches_reference_formula():
     """BaseResidualLoss(use_l1=False, use_silog=False): the reference's recon term is F.mse_loss over the valid pixels
     (utils_base_residual_loss.py:60-65, 118-131).  Checked against that formula in torch (value and d loss/d final)."""
@@ -165,6 +194,10 @@ def test_mse_reconstruction_variant_matches_reference_formula():
     K.loss_stats(fd, gd, 1.0, mm, 1e-6, stats, ws)
     K.loss_finish(fd, gd, 1.0, mm, 1e-6, stats, code, 0.7, 0.0, 0.5, lo, gr)
     assert rel_err(gr, gref) <= 1e-5
+    # loss-only call (grad = None): the MSE value must still be written (round-2 advisor finding: it was skipped)
+    lo2 = torch.full((1,), -1.0, device=DEV)
+    K.loss_finish(fd, gd, 1.0, mm, 1e-6, stats, code, 0.7, 0.0, 0.5, lo2, None)
+    assert float(lo2) == float(lo) and abs(float(lo2) - 0.7 * float(rec)) <= 2e-5 * 0.7 * float(rec)
     with pytest.raises(RuntimeError, match='criterion 4'):
         K.loss_finish(fd, gd, 1.0, 1, 1e-6, stats, 4, 0.7, 0.0, 0.5, lo, gr)
 

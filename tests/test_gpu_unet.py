@@ -456,6 +456,40 @@ def test_graph_step_survives_another_batch_shape():
     assert torch.equal(evals[0], evals[1])            # eval after replays sees the freshly packed weights
 
 
+@pytest.mark.parametrize('fused_dz', [True, False])
+def test_graph_step_survives_a_ragged_TRAIN_step(fused_dz, monkeypatch):
+    """Round-2 advisor finding: the trainer's own loss / gradient scratch (FusedTrainer.gout) was reallocated when an eager
+    step with another batch shape ran between two replays, and the captured graph kept writing into the freed block.
+    The scratch is now kept per batch shape; a ragged trainer.step between replays must leave the run bit-identical to
+    the eager one (fused_dz = False takes the path where the captured loss kernel writes ``gout``)."""
+    from audio_depth_estimation_amd.engine import FusedTrainer
+    if not fused_dz:
+        monkeypatch.setenv('ADN_NO_FUSED_DZ', '1')
+    g = torch.Generator().manual_seed(6)
+    audio = torch.rand(4, 2, 128, 128, generator=g).to(DEV)
+    gt = (30 * torch.rand(4, 1, 128, 128, generator=g)).to(DEV)
+    finals = []
+    for mode in ('eager', 'graph'):
+        torch.manual_seed(0)
+        model = _build('unet_128', 64, False, torch.bfloat16)
+        with torch.no_grad():
+            model.model.model[3].bias.fill_(1.0)
+        model.train()
+        tr = FusedTrainer(model.engine(), 'Combined', 0.237, 0.637, 0.869, lr=0.002, clip_norm=1.0)
+        if mode == 'graph':
+            tr.enable_graph(after_steps=1)
+        for it in range(7):
+            tr.step(audio, gt)
+            if it in (2, 4):
+                tr.step(audio[:3], gt[:3])                       # ragged last batch of an epoch: eager, other shape
+                junk = [torch.full((3, 1, 128, 128), float('nan'), device=DEV) for _ in range(4)]   # reuse freed blocks, if any
+                del junk
+        torch.cuda.synchronize()
+        finals.append(model.engine().flat_p.detach().clone())
+    assert torch.isfinite(finals[1]).all()
+    assert torch.equal(finals[0], finals[1])
+
+
 def test_load_state_dict_after_fused_steps_refreshes_the_bf16_mirror():
     """after fused steps (which leave the bf16 operand mirror marked fresh) a load_state_dict must
     invalidate it: eval predictions equal those of a fresh model holding the same weights."""
