@@ -355,3 +355,47 @@ def test_b32_train_step_against_the_reference(dtype):
             assert int(gotv) == int(ref_v), k
         else:
             assert float((gotv - ref_v).abs().max()) <= (1e-4 if f32 else 2e-2) * float(ref_v.abs().max()) + 1e-6, k
+
+
+def test_bf16_training_tracks_the_exact_f32_path_over_300_steps():
+    """the headline dtype must TRAIN like the exact path, not only match it for one step.  300 fused steps
+    (unet_256 ngf 64, B = 32, Combined loss, clip 1.0, AdamW lr 2e-3 -- conf/mode/train.yaml) on a fixed synthetic stream of
+    300 DIFFERENT batches (seeded on the device; depth = a smooth function of the spectrogram + 1 m of noise, ~10 % invalid
+    pixels), once in bf16 and once on the exact-f32 MFMA path, from the same initial weights.  Stated band: the window means
+    of the loss (12 windows of 25 steps) agree within 1 % at every window, and both runs descend by more than 4x
+    (train.py:633-691).  Measured: <= 0.33 % (1.5617 -> 0.2342 in both).  (On a stream that repeats 8 batches the loss falls
+    to 0.015 and the f32 run shows a loss spike at step ~200 that the bf16 run does not: the trajectories of an over-fitted
+    run decorrelate, which says nothing about the arithmetic -- hence 300 different batches.)"""
+    from audio_depth_estimation_amd.engine import FusedTrainer
+
+    def batch(it):
+        g = torch.Generator(device=DEV).manual_seed(4321 + it)
+        audio = torch.rand(B, 2, S, S, generator=g, device=DEV)
+        noise = torch.randn(B, 1, S, S, generator=g, device=DEV)
+        drop = torch.rand(B, 1, S, S, generator=g, device=DEV) < 0.1
+        gt = 3 + 24 * torch.nn.functional.avg_pool2d(audio.mean(1, keepdim=True), 9, 1, 4) + noise
+        return audio, torch.where(drop, torch.zeros_like(gt), gt.clamp(3.0, 30.0))
+
+    curves = {}
+    for dtype in (torch.bfloat16, torch.float32):
+        model = _model(dtype)
+        with torch.no_grad():
+            model.model.model[3].bias.fill_(4.0)
+        model.train()
+        tr = FusedTrainer(model.engine(), 'Combined', 0.237, 0.637, 0.869, max_depth=30.0, optimizer='AdamW', lr=0.002,
+                          clip_norm=1.0)
+        losses = torch.zeros(300, device=DEV)
+        for it in range(300):
+            loss, _ = tr.step(*batch(it))
+            losses[it] = loss
+        curves[dtype] = losses.cpu().view(12, 25).mean(1)
+        del tr, model
+        torch.cuda.empty_cache()
+    a, b = curves[torch.bfloat16], curves[torch.float32]
+    rel = ((a - b).abs() / b.abs()).tolist()
+    print('bf16 windows', [round(v, 4) for v in a.tolist()])
+    print('f32  windows', [round(v, 4) for v in b.tolist()])
+    print('relative difference per window', [round(v, 4) for v in rel])
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    assert float(b[-1]) < 0.25 * float(b[0]) and float(a[-1]) < 0.25 * float(a[0])      # both trained
+    assert max(rel) <= 0.01, rel
