@@ -442,3 +442,126 @@ def test_resume_from_a_checkpoint_written_by_the_reference():
                               weight_decay=wd)
     probe.load_state_dict(sd)
     assert float(sd['state'][0]['step']) == 3
+
+
+# ---- full width, 256 x 256, against numbers produced by the reference (tests/golden/make_golden_fullsize_dc.py) ------------
+def _hash_key(key):
+    h = 0
+    for ch in key:
+        h = (h * 131 + ord(ch)) % (2 ** 31 - 1)
+    return h
+
+
+def _perturb_by_name(model):
+    """The generator's `perturb`: BatchNorm affine, attention gate and attention biases as a function of the tensor NAME."""
+    with torch.no_grad():
+        for k, v in model.state_dict().items():
+            g = torch.Generator().manual_seed(_hash_key(k))
+            if k.endswith('.gamma'):
+                v.fill_(0.5)
+            elif 'attention_modules' in k and k.endswith('.bias'):
+                v.copy_(0.1 * torch.randn(v.shape, generator=g))
+            elif v.dim() == 1 and k.endswith('.weight'):
+                v.copy_(1.0 + 0.2 * torch.randn(v.shape, generator=g))
+            elif v.dim() == 1 and k.endswith('.bias') and ('double_conv' in k or 'fusion' in k):
+                v.copy_(0.1 * torch.randn(v.shape, generator=g))
+
+
+def _fullsize_check(z, model, tr, loss, pred, f32, pred_tol, grad_tol, skip=lambda k: False):
+    idx = torch.from_numpy(z['idx'])
+    ref = torch.from_numpy(z['pred_val'])
+    relp = float((pred.reshape(-1).float().cpu()[idx] - ref).abs().sum() / ref.abs().sum())
+    lrel = abs(loss.item() - float(z['loss'])) / abs(float(z['loss']))
+    dref = torch.from_numpy(z['pred_grad_val'])
+    reld = float((tr.gout.reshape(-1).float().cpu()[idx] - dref).abs().sum() / dref.abs().sum())
+    eng, worst = model.engine(), {}
+    for k, prm in model.named_parameters():
+        gn_ref = float(z['gnorm/' + k])
+        if skip(k) or gn_ref < 1e-12:
+            continue
+        gflat = eng.grad_view(prm).detach().float().cpu().reshape(-1)
+        g = torch.Generator().manual_seed(_hash_key(k))
+        si = torch.randint(0, gflat.numel(), (min(512, gflat.numel()),), generator=g)
+        rms = gn_ref / (gflat.numel() ** 0.5)
+        err = float((gflat[si] - torch.from_numpy(z['gsample/' + k])).norm() / (len(si) ** 0.5)) / rms
+        worst[k] = (err, abs(float(gflat.double().norm()) - gn_ref) / gn_ref)
+    top = sorted(worst.items(), key=lambda kv: -kv[1][0])[:4]
+    print(f'pred rel-L1 {relp:.3e} loss rel {lrel:.3e} dloss/dpred rel-L1 {reld:.3e}; worst gradients {top}')
+    assert relp <= pred_tol, relp
+    assert lrel <= (1e-5 if f32 else 2e-3), lrel
+    assert reld <= (1e-4 if f32 else 8e-2), reld
+    for k, (err, nerr) in worst.items():
+        scalar = 8.0 if k.endswith('.gamma') else 1.0      # one scalar = a 4 M-term sum of mixed signs (measured 1.5 % in f32)
+        assert err <= scalar * grad_tol[0] and nerr <= scalar * grad_tol[1], (k, err, nerr)
+
+
+def _seed_weights_match(model, z):
+    for k, v in model.state_dict().items():
+        if v.dtype.is_floating_point:
+            assert abs(float(v.double().sum()) - float(z['init_sum/' + k])) <= 1e-6 * max(1.0, float(z['init_abs/' + k])), k
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_rgb_full_width_256_against_the_reference(dtype):
+    """RGBDepthNet base 64 at 256 x 256, B = 2 (rgb_bc64_256.npz: the reference's create_rgb_depth_model + DepthLoss run on
+    the CPU): the patch-staged 3 x 3 MFMA kernels at their real tilings against reference NUMBERS.
+    f32: prediction rel-L1 <= 1e-4 (measured 6e-6), every gradient tensor sampled rel-L2 <= 2e-2 (1.0e-2) and norm within
+    5e-3 (1.6e-3).  bf16 (18 conv stages in a freshly initialised BatchNorm stack amplify every rounding ~1.7x per stage,
+    DESIGN section 2): prediction <= 8e-2 (4.7e-2), d loss / d pred <= 8e-2 (3.4e-2), gradient norms within 15 % (<= 6.7 %)
+    -- the per-ELEMENT gradient error of the deep tensors is of the order of the gradient itself (sampled rel-L2 0.69, bound
+    1.0): what bf16 keeps at this depth and width is the norm and the training behaviour (test_gpu_config5's descent tests),
+    the tight statement about the kernels is the f32 row."""
+    from audio_depth_estimation_amd.engine import FusedTrainer
+    z = np.load(os.path.join(GOLDEN, 'rgb_bc64_256.npz'))
+    bc, S, B = [int(v) for v in z['meta']]
+    max_depth, l1w, sw = [float(v) for v in z['hyper']]
+    torch.manual_seed(0)
+    model = _rgb(bc, S, dtype, None, max_depth)
+    _seed_weights_match(model, z)
+    _perturb_by_name(model)
+    with torch.no_grad():
+        model.outc.bias.fill_(2.0)
+    g = torch.Generator().manual_seed(1234)
+    image = torch.rand(B, 3, S, S, generator=g)
+    gt = max_depth * torch.rand(B, 1, S, S, generator=g)
+    gt[gt < 0.1 * max_depth] = 0.0
+    model.train()
+    tr = FusedTrainer(model.engine(), 'DepthLoss', l1w, sw, 0.0, max_depth=max_depth, optimizer='AdamW', lr=1e-6,
+                      clip_norm=None)
+    loss, pred = tr.step(image.to(DEV), gt.to(DEV))
+    f32 = dtype == torch.float32
+    _fullsize_check(z, model, tr, loss, pred, f32, 1e-4 if f32 else 8e-2, (2e-2, 5e-3) if f32 else (1.0, 0.15))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_binaural_level2_attention_16384_tokens_against_the_reference(dtype):
+    """BinauralAttentionDepthNet base 64 at 256 x 256 with the LEVEL-2 cross-attention (C = 128, 128 x 128 = 16 384 tokens per
+    direction, gamma = 0.5), B = 1, against binaural_l2_bc64_256.npz -- numbers from the reference's own module, which
+    materialises the two 16 384 x 16 384 score matrices (models/binaural_attention_model.py:106-153).  Replaces "constant V /
+    linear in dO" at this size with "equal to the reference" (VERDICT r2 item 2b): prediction, loss, d loss / d pred and every
+    gradient (query / key / value / out / gamma of the attention module included).  f32 (generic exact attention kernels):
+    prediction rel-L1 <= 1e-4 (measured 1.6e-6), gradients sampled rel-L2 <= 2e-2 (<= 1e-2; the scalar gamma 1.5 %, bound
+    8x).  bf16 (the MFMA attention kernels): prediction <= 4e-2 (1.5e-2), d loss / d pred <= 8e-2 (2.2e-2), gradient norms
+    within 20 % (<= 13 %), per-element error of the deepest (first-layer) tensors of the order of the gradient (0.86, bound
+    1.0) -- see the RGB test above for what that bound does and does not say."""
+    from audio_depth_estimation_amd.engine import FusedTrainer
+    z = np.load(os.path.join(GOLDEN, 'binaural_l2_bc64_256.npz'))
+    bc, S, B = [int(v) for v in z['meta']]
+    max_depth, l1w, sw, lam = [float(v) for v in z['hyper']]
+    torch.manual_seed(0)
+    model = _binaural(bc, S, dtype, None, max_depth, levels=(2,))
+    _seed_weights_match(model, z)
+    _perturb_by_name(model)
+    with torch.no_grad():
+        model.outc[0].weight.mul_(0.1)          # keeps the predictions away from SIlog's 1 / pred singularity (generator script)
+    g = torch.Generator().manual_seed(1234)
+    audio = torch.rand(B, 2, S, S, generator=g)
+    gt = max_depth * torch.rand(B, 1, S, S, generator=g)
+    gt[gt < 0.1 * max_depth] = 0.0
+    model.train()
+    tr = FusedTrainer(model.engine(), 'Combined', l1w, sw, lam, max_depth=max_depth, optimizer='AdamW', lr=1e-6,
+                      clip_norm=None, mask_mode='gt0')
+    loss, pred = tr.step(audio.to(DEV), gt.to(DEV))
+    f32 = dtype == torch.float32
+    _fullsize_check(z, model, tr, loss, pred, f32, 1e-4 if f32 else 4e-2, (2e-2, 5e-3) if f32 else (1.0, 0.2),
+                    skip=_noise_bias)
