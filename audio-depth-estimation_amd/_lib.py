@@ -89,6 +89,7 @@ _PROTOS = {
     'adn_last_error': (C.c_char_p, []),
     'adn_version': (C.c_int, []),
     'adn_debug_poison_lds': (C.c_int, [c_void_p]),
+    'adn_debug_stream_rmw': (C.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p]),
     'adn_igemm_num_partials': (c_int64, [C.POINTER(AdnIgemmDesc)]),
     'adn_igemm_workspace_bytes': (c_int64, [C.POINTER(AdnIgemmDesc)]),
     'adn_igemm': (C.c_int, [C.POINTER(AdnIgemmDesc), c_void_p]),
@@ -202,6 +203,7 @@ _PROTOS = {
     'adn_sum_to_scalar': (C.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
     'adn_grad_norm': (C.c_int, [c_void_p, c_int64, c_float, c_void_p, c_void_p, c_int64, c_void_p]),
     'adn_grad_norm_workspace_bytes': (c_int64, [c_int64]),
+    'adn_grad_sqsum_partials': (C.c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     'adn_grad_norm_ranges': (C.c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_float, c_void_p, c_void_p,
                                        c_int64, c_void_p]),
     'adn_optimizer_step': (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_float,
@@ -285,8 +287,14 @@ def annotate(**meta):
 
 
 def record_py(fn):
-    """Run a Python action now and, while recording, make it part of the launch plan."""
-    fn()
+    """Run a Python action now and, while recording, make it part of the launch plan (as ONE entry: library calls the
+    action makes itself -- the reducer's per-bucket norm -- are not recorded a second time)."""
+    global RECORD
+    saved, RECORD = RECORD, None
+    try:
+        fn()
+    finally:
+        RECORD = saved
     if RECORD is not None:
         RECORD.append((None, fn, 'py', {}))
 

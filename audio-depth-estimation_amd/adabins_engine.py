@@ -139,9 +139,13 @@ class FeatureLoss(Op):
         pass
 
     def bwd(self, eng):
+        a = self.src
+        extra = eng.feat_extra[self.level] if eng.feat_extra is not None else None
+        if extra is not None:                   # autograd path: upstream gradient of the returned feature, NHWC f32
+            K.bcast_add(a.grad.view(-1, 1, 1, a.C), extra.view(-1, a.C), 1.0, accumulate=a.written)
+            a.written = True
         if eng.feat_coef is None:
             return
-        a = self.src
         assert a.written
         t = eng.branches['rgb'].feats[self.level]
         K.featcos_grad(a.data, t.data, eng.feat_stats[self.level], eng.feat_coef[self.level], a.grad)
@@ -160,6 +164,8 @@ class AdaBinsEngine(DCEngine):
         self.step_counter = None     # device f64[1] step count (the trainer's optimizer state): fresh dropout per replay
         self.feat_coef = None
         self.feat_stats = None
+        self.feat_extra = None       # autograd path: upstream gradients of x1..x5 (see backward_leaves)
+        self.autograd_pass = 0       # forward count of the student branch: a stale backward is refused
         self.branches = {}
 
     def bind_parameters(self):
@@ -308,7 +314,7 @@ class AdaBinsEngine(DCEngine):
                 'base_depth': base, 'residual': resid, 'final_depth': final}
 
     # ------------------------------------------------------------------ backward of the student
-    def backward_student(self, dbase, dres, dmean, dcent_extra):
+    def backward_student(self, dbase, dres, dmean, dcent_extra, logits_extra=None):
         br = self.branches['audio']
         for a in br.acts:
             a.written = False
@@ -318,10 +324,113 @@ class AdaBinsEngine(DCEngine):
         K.bins_bwd(br.logits.data, br.centers, br.base, dbase, dmean, br.logits.grad, br.dcent, self.workspace)
         if dcent_extra is not None:
             K.bcast_add(br.dcent.view(self.B, 1, 1, -1), dcent_extra, 1.0, accumulate=True)
+        if logits_extra is not None:                     # upstream gradient of the returned bin_logits, NHWC f32
+            lg = br.logits
+            K.bcast_add(lg.grad.view(-1, 1, 1, lg.C), logits_extra.view(-1, lg.C), 1.0, accumulate=True)
         br.class_op.bwd(self)
         for op in reversed(br.ops):
             if op.out.needs_grad:
                 op.bwd(self)
+
+
+def _f32_add_(dst, src):
+    """dst += src for flat f32 device tensors (adn_bcast_add with one pixel per row)."""
+    K.bcast_add(dst.view(-1, 1, 1, 1), src.contiguous().view(-1, 1), 1.0, accumulate=True)
+
+
+def _backward_leaves(eng, g_feats, g_centers, g_logits, g_base, g_res, g_final):
+    """Backward of the student branch from upstream gradients of the tensors forward() returned (any may be None):
+    g_feats 5 x [B,C,h,w], g_centers [B,nb], g_logits [B,nb,H,W], g_base / g_res / g_final [B,1,H,W], all f32 NCHW.
+    final = clamp(base + residual, 0, max_depth) (adabins_distillation_model.py:389-391) routes g_final into both."""
+    br, m = eng.branches['audio'], eng.module
+    B, H, W = eng.B, br.logits.H, br.logits.W
+    f32 = dict(dtype=torch.float32, device=eng.dev)
+    dbase = torch.zeros(B * H * W, **f32)
+    dres = torch.zeros(B * H * W, **f32)
+    if g_final is not None:
+        s = br.base.clone()
+        _f32_add_(s, br.head.result)
+        masked = torch.empty_like(s)
+        K.clamp_range(s, m.max_depth, masked, g=g_final.contiguous().float().view(-1))
+        _f32_add_(dbase, masked)
+        _f32_add_(dres, masked)
+    if g_base is not None:
+        _f32_add_(dbase, g_base.float())
+    if g_res is not None:
+        _f32_add_(dres, g_res.float())
+    eng.feat_extra = None
+    if any(g is not None for g in g_feats):
+        eng.feat_extra = []
+        for g, a in zip(g_feats, br.feats):
+            if g is None:
+                eng.feat_extra.append(None)
+                continue
+            t = torch.empty(B, a.H, a.W, a.C, **f32)
+            K.nchw_to_nhwc(g.contiguous().float(), t)
+            eng.feat_extra.append(t)
+    saved = eng.feat_coef, eng.feat_stats
+    eng.feat_coef, eng.feat_stats = None, None
+    glog = None
+    if g_logits is not None:
+        glog = torch.empty(B, H, W, m.n_bins, **f32)
+        K.nchw_to_nhwc(g_logits.contiguous().float(), glog)
+    br.dmean.zero_()
+    try:
+        eng.backward_student(dbase, dres, br.dmean, g_centers.contiguous().float() if g_centers is not None else None,
+                             logits_extra=glog)
+    finally:
+        eng.feat_extra = None
+        eng.feat_coef, eng.feat_stats = saved
+
+
+class _StudentFunction(torch.autograd.Function):
+    """torch.autograd bridge of the student branch: the parameters are inputs, the outputs are the leaves of the
+    reference's output dict (x1..x5, bin_centers, bin_widths, bin_logits, base_depth, residual, final_depth), so the
+    reference's own loop -- ``loss, _ = criterion(model(audio, rgb), gt, mask); loss.backward(); clip; optimizer.step()``
+    (train_adabins_distillation.py:445-456) -- runs unchanged.  The fused AdaBinsTrainer stays the fast path."""
+
+    @staticmethod
+    def forward(ctx, audio, engine, *params):
+        eng = engine
+        eng._prepare_branches(audio.shape[0], audio.shape[2], audio.shape[3], audio.device)
+        if eng.resize_to is not None:
+            raise NotImplementedError('autograd through AdaBinsDistillationModel needs output_size == input size '
+                                      '(call under torch.no_grad() for the forward values)')
+        br = eng.branches['audio']
+        eng._forward_branch(br, audio, True)
+        eng._finalize_plain(br)
+        eng.autograd_pass += 1
+        ctx.engine, ctx.stamp = eng, eng.autograd_pass
+        ctx.set_materialize_grads(False)
+        o = eng._outputs(br)
+        leaves = tuple(o['features'][f'x{i}'] for i in range(1, 6)) + (o['bin_centers'], o['bin_widths'], o['bin_logits'],
+                                                                       o['base_depth'], o['residual'], o['final_depth'])
+        ctx.mark_non_differentiable(o['bin_widths'])      # the centres carry the predictor's gradient (:143-149)
+        return leaves
+
+    @staticmethod
+    def backward(ctx, *g):
+        eng = ctx.engine
+        if ctx.stamp != eng.autograd_pass:
+            raise RuntimeError('AdaBinsDistillationModel: backward through a forward whose activations were overwritten '
+                               'by a later training forward of the same module')
+        _backward_leaves(eng, g[0:5], g[5], g[7], g[8], g[9], g[10])
+        off = eng.train_offset
+        return (None, None) + tuple(eng.grad_view(p) if (o >= off and p.requires_grad) else None
+                                    for p, o, _ in eng.param_meta)
+
+
+def run_student(engine, audio, training):
+    """forward_audio of the module: differentiable outputs in training mode under grad, plain values otherwise."""
+    if not engine._bound():
+        engine.bind_parameters()
+    off = engine.train_offset
+    if training and torch.is_grad_enabled() and any(p.requires_grad for p, o, _ in engine.param_meta if o >= off):
+        v = _StudentFunction.apply(audio, engine, *[p for p, _, _ in engine.param_meta])
+        feats = {f'x{i + 1}': v[i] for i in range(5)}
+        return {'features': feats, 'bin_centers': v[5], 'bin_widths': v[6], 'bin_logits': v[7], 'base_depth': v[8],
+                'residual': v[9], 'final_depth': v[10]}
+    return engine.run_branch('audio', audio, training)
 
 
 def _update_again(self, eng):
@@ -383,12 +492,15 @@ class AdaBinsTrainer(GraphedStep):
         self.exp_avg = torch.zeros_like(eng.flat_p)
         self.exp_avg_sq = torch.zeros_like(eng.flat_p)
         eng.step_counter = self.state
+        self.bucket_norm = None
         if self.ddp is not None:
             # only the student's gradients (the suffix of the flat buffer) are exchanged: the teacher never trains
             off = eng.train_offset
             self._ddp_view = _GradView(eng.flat_g[off:])
             self.ddp.attach(self._ddp_view)
             eng.on_grad_ready = lambda lo: self._ddp_view.on_grad_ready(max(0, lo - off))
+            if self.clip_norm is not None and eng.flat_g.is_cuda:
+                self.bucket_norm = self.ddp.enable_bucket_norm()
         self._ready = True
 
     def enable_graph(self, after_steps=3):
@@ -487,7 +599,9 @@ class AdaBinsTrainer(GraphedStep):
             self.ddp.finish()
         off = eng.train_offset
         p, g = eng.flat_p[off:], eng.flat_g[off:]
-        if self.clip_norm is not None:
+        if self.clip_norm is not None and self.bucket_norm is not None:
+            K.grad_norm_ranges(g, None, self.bucket_norm, float(self.clip_norm), self.state, self.norm_ws)
+        elif self.clip_norm is not None:
             K.grad_norm(g, float(self.clip_norm), self.state, self.norm_ws)
         K.optimizer_step(p, g, self.exp_avg[off:], self.exp_avg_sq[off:], self.opt_kind, self.lr, self.betas[0],
                          self.betas[1], self.eps, self.weight_decay, self.clip_norm is not None, self.state,

@@ -107,6 +107,52 @@ class BaseResidualEngine(DCEngine):
                 op.bwd(self)
 
 
+class _BaseResidualFunction(torch.autograd.Function):
+    """torch.autograd bridge: parameters are inputs, the outputs are (base_depth, residual, final_depth), so
+    ``criterion(base, res, final, gt, mask)[0].backward()`` of train_base_residual.py reaches the parameters.
+    final = clamp(base + residual, 0, max_depth) (base_residual_model.py:150-152) routes its gradient into both heads."""
+
+    @staticmethod
+    def forward(ctx, x, engine, *params):
+        b, r, f = engine.forward_net(x, True)
+        engine.autograd_pass = getattr(engine, 'autograd_pass', 0) + 1
+        ctx.engine, ctx.stamp = engine, engine.autograd_pass
+        ctx.set_materialize_grads(False)
+        return b.clone(), r.clone(), f.clone()
+
+    @staticmethod
+    def backward(ctx, g_base, g_res, g_final):
+        eng = ctx.engine
+        if ctx.stamp != eng.autograd_pass:
+            raise RuntimeError('BaseResidualDepthNet: backward through a forward whose activations were overwritten by a '
+                               'later training forward of the same module')
+        base, resid = eng.head_base.result, eng.head_res.result
+        add_ = lambda dst, src: K.bcast_add(dst.view(-1, 1, 1, 1), src.contiguous().float().view(-1, 1), 1.0, accumulate=True)
+        dbase, dres = torch.zeros_like(base), torch.zeros_like(resid)
+        if g_final is not None:
+            s = base.clone()
+            add_(s, resid)
+            masked = torch.empty_like(s)
+            K.clamp_range(s, eng.module.max_depth, masked, g=g_final.contiguous().float())
+            add_(dbase, masked)
+            add_(dres, masked)
+        if g_base is not None:
+            add_(dbase, g_base)
+        if g_res is not None:
+            add_(dres, g_res)
+        eng.backward_net(dbase, dres)
+        return (None, None) + tuple(eng.grad_view(p) if p.requires_grad else None for p, _, _ in eng.param_meta)
+
+
+def run_base_residual(engine, x, training):
+    if not engine._bound():
+        engine.bind_parameters()
+    if training and torch.is_grad_enabled() and any(p.requires_grad for p, _, _ in engine.param_meta):
+        return _BaseResidualFunction.apply(x, engine, *[p for p, _, _ in engine.param_meta])
+    with torch.no_grad():
+        return engine.run(x, training)
+
+
 class BaseResidualTrainer(GraphedStep):
     """One fused step of train_base_residual.py:375-388: forward, BaseResidualLoss (valid = gt > 0), backward,
     clip_grad_norm_(1.0), optimizer."""
@@ -188,8 +234,12 @@ class BaseResidualTrainer(GraphedStep):
                              dbase=torch.empty_like(pred), dres=torch.empty_like(pred))
         for name in self._SCRATCH:
             setattr(self, name, sets[key][name])
-        if self.ddp is not None and not self._ready:
-            self.ddp.attach(eng)
+        if not self._ready:
+            self.bucket_norm = None
+            if self.ddp is not None:
+                self.ddp.attach(eng)
+                if self.clip_norm is not None and eng.flat_g.is_cuda:
+                    self.bucket_norm = self.ddp.enable_bucket_norm()
         self._ready = True
 
     def state_dict(self):
@@ -234,7 +284,9 @@ class BaseResidualTrainer(GraphedStep):
         eng.backward_net(self.dbase, self.dres)
         if self.ddp is not None:
             self.ddp.finish()
-        if self.clip_norm is not None:
+        if self.clip_norm is not None and self.bucket_norm is not None:
+            K.grad_norm_ranges(eng.flat_g, None, self.bucket_norm, float(self.clip_norm), self.state, self.norm_ws)
+        elif self.clip_norm is not None:
             K.grad_norm(eng.flat_g, float(self.clip_norm), self.state, self.norm_ws)
         K.optimizer_step(eng.flat_p, eng.flat_g, self.exp_avg, self.exp_avg_sq, self.opt_kind, self.lr, self.betas[0],
                          self.betas[1], self.eps, self.weight_decay, self.clip_norm is not None, self.state,

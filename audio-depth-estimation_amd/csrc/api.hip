@@ -39,3 +39,27 @@ extern "C" int adn_debug_poison_lds(void* stream) {
   ADN_CHECK_LAUNCH();
   return ADN_OK;
 }
+
+
+// ---- measurement aid: an HBM stream on a fixed number of CUs ----------------------------------------------------------
+// What an RCCL ring all-reduce does to THIS GPU's memory system while the backward pass runs beside it: a few dozen
+// workgroups streaming the gradient buffer out and a peer's data in.  tools/overlap_experiment.py launches it on a side
+// stream with 16 / 32 / 64 workgroups to price "exchange overlapped with backward" against "exchange after backward" on one
+// GPU.  dst[i] = src[i] + dst[i] over `bytes` (16-byte accesses, grid-stride), `passes` times.
+namespace {
+__global__ __launch_bounds__(256) void stream_rmw_kernel(const u32x4_t* src, u32x4_t* dst, int64_t n16, int passes) {
+  for (int ps = 0; ps < passes; ++ps)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) {
+      const u32x4_t a = src[i], b = dst[i];
+      dst[i] = u32x4_t{a[0] + b[0], a[1] + b[1], a[2] + b[2], a[3] + b[3]};
+    }
+}
+}  // namespace
+
+extern "C" int adn_debug_stream_rmw(const void* src, void* dst, int64_t bytes, int32_t workgroups, int32_t passes, void* stream) {
+  ADN_CHECK_ARG(src && dst && bytes >= 16 && bytes % 16 == 0 && workgroups > 0 && passes > 0, "adn_debug_stream_rmw: bad arguments");
+  hipLaunchKernelGGL(stream_rmw_kernel, dim3(workgroups), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const u32x4_t*>(src), reinterpret_cast<u32x4_t*>(dst), bytes / 16, passes);
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}

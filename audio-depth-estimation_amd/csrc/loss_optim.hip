@@ -420,6 +420,20 @@ extern "C" int adn_grad_norm(const float* grads, int64_t n, float max_norm, doub
   return ADN_OK;
 }
 
+// First half of adn_grad_norm alone: the sums of squares of one slice of the gradient buffer as
+// adn_grad_norm_workspace_bytes(n) / 8 doubles.  The data-parallel step calls it per bucket as the bucket's all-reduce
+// lands (the pass hides behind the collectives still in flight) and finishes with adn_grad_norm_ranges(extra = all slots).
+extern "C" int adn_grad_sqsum_partials(const float* grads, int64_t n, double* partials, int64_t partials_bytes,
+                                       void* stream) {
+  ADN_CHECK_ARG(grads && n > 0 && partials, "adn_grad_sqsum_partials: bad arguments");
+  const unsigned nb = red_blocks(n);
+  ADN_CHECK_ARG(partials_bytes >= (int64_t)nb * 8, "adn_grad_sqsum_partials: partials buffer too small");
+  ADN_CHECK_ARG((reinterpret_cast<uintptr_t>(grads) & 15) == 0, "adn_grad_sqsum_partials: grads must be 16-byte aligned");
+  hipLaunchKernelGGL(sqsum_partial_kernel, dim3(nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), grads, n, partials);
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}
+
 extern "C" int adn_grad_norm_ranges(const float* grads, const int64_t* ranges, int32_t n_ranges, const double* extra,
                                     int32_t n_extra, float max_norm, double* state, void* workspace,
                                     int64_t workspace_bytes, void* stream) {

@@ -18,8 +18,11 @@ bound; 217.6 MB of U-Net gradients go out as a few large (default 32 MiB) bucket
 per-tensor messages.  Works with the gloo backend on CPU tensors too (tests, world_size 2).
 Optional ``payload='bf16'``: every bucket is cast to bf16 before the exchange and back afterwards (108.8 MB instead of
 217.6 MB on the links for the U-Net; SURVEY section 5: the exchange time decides the 8-GPU scaling target).  The SUM then
-runs in bf16 -- about 3 significant digits per element, the order of the bf16 compute path's own gradient error; the
-default stays f32, which is what the parity tests (bit-identical replicas vs a single-process emulation) pin.
+runs in bf16 -- about 3 significant digits per element, the order of the bf16 compute path's own gradient error -- and
+finish() OVERWRITES the f32 gradients with that bf16 sum; the default stays f32, which is what the parity tests
+(bit-identical replicas vs a single-process emulation) pin.
+Clip norm: ``enable_bucket_norm()`` makes finish() take the sum of squares of each bucket as its collective lands
+(adn_grad_sqsum_partials), so the norm pass over the reduced gradients overlaps the buckets still in flight.
 """
 from __future__ import annotations
 
@@ -41,6 +44,7 @@ class GradientAllReducer:
         self.flat_g = None
         self._next = 0
         self._works = []
+        self.norm_slots = None     # f64 partial sums of squares per bucket (enable_bucket_norm)
 
     @property
     def world_size(self):
@@ -60,6 +64,19 @@ class GradientAllReducer:
         self._next = 0
         self._works = []
         self.g16 = torch.empty(n, dtype=torch.bfloat16, device=self.flat_g.device) if self.payload == 'bf16' else None
+
+    def enable_bucket_norm(self):
+        """Take the clip norm bucket by bucket: finish() leaves the sums of squares of every reduced bucket in
+        ``norm_slots`` (f64), computed as each collective lands while the later ones are still on the links, instead
+        of one pass over the whole gradient buffer after the exchange (device tensors only).  Returns the slots."""
+        from . import kernels as K
+        counts = [K.grad_sqsum_count(hi - lo) for lo, hi in self.buckets]
+        self._slot_ranges, at = [], 0
+        for c in counts:
+            self._slot_ranges.append((at, at + c))
+            at += c
+        self.norm_slots = torch.zeros(at, dtype=torch.float64, device=self.flat_g.device)
+        return self.norm_slots
 
     def broadcast_parameters(self, flat_p, src=0):
         """Replicate rank ``src``'s weights (what DataParallel.replicate does every forward; once here)."""
@@ -88,10 +105,14 @@ class GradientAllReducer:
     def finish(self):
         """Flush the remaining buckets and make the compute stream wait for all collectives."""
         self.on_grad_ready(0)
-        for w, lo, hi in self._works:
+        for i, (w, lo, hi) in enumerate(self._works):
             w.wait()                              # the compute stream now waits for the collective's stream
             if self.g16 is not None:
                 self.flat_g[lo:hi].copy_(self.g16[lo:hi])
+            if self.norm_slots is not None:
+                from . import kernels as K
+                a, b = self._slot_ranges[i]
+                K.grad_sqsum_partials(self.flat_g[lo:hi], self.norm_slots[a:b])
         self._works = []
 
 

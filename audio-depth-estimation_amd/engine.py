@@ -557,8 +557,11 @@ class FusedTrainer:
         self.gout = None
         self._gout_sets = {}
         self._flat_id = eng.flat_p.data_ptr()
+        self.bucket_norm = None
         if self.ddp is not None:
             self.ddp.attach(eng)
+            if self.clip_norm is not None and eng.flat_g.is_cuda:
+                self.bucket_norm = self.ddp.enable_bucket_norm()      # sums of squares per reduced bucket (ddp.finish)
         self._ready = True
 
     def state_dict(self):
@@ -695,6 +698,8 @@ class FusedTrainer:
             _lib.record_py(self.ddp.finish)
         if fused:
             K.grad_norm_ranges(eng.flat_g, eng.norm_ranges, eng.sq_all, float(self.clip_norm), self.state, self.norm_ws)
+        elif self.clip_norm is not None and self.bucket_norm is not None:
+            K.grad_norm_ranges(eng.flat_g, None, self.bucket_norm, float(self.clip_norm), self.state, self.norm_ws)
         elif self.clip_norm is not None:
             K.grad_norm(eng.flat_g, float(self.clip_norm), self.state, self.norm_ws)
         K.optimizer_step(eng.flat_p, eng.flat_g, self.exp_avg, self.exp_avg_sq, self.opt_kind, self.lr,

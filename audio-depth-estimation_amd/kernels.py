@@ -459,6 +459,17 @@ def grad_norm(grads, max_norm, state, workspace):
               workspace.numel() * workspace.element_size(), _stream())
 
 
+def grad_sqsum_count(n):
+    """Number of f64 partial sums adn_grad_sqsum_partials writes for n elements."""
+    return _lib.load().adn_grad_norm_workspace_bytes(n) // 8
+
+
+def grad_sqsum_partials(grads, partials):
+    """partials f64[grad_sqsum_count(n)] <- sums of squares of the f32 slice ``grads`` (one all-reduce bucket)."""
+    _dev(grads, partials)
+    _lib.call('adn_grad_sqsum_partials', ptr(grads), grads.numel(), ptr(partials), _nbytes(partials), _stream())
+
+
 def grad_norm_ranges(grads, ranges, extra, max_norm, state, workspace):
     """Total gradient norm + clip coefficient from (a) ``ranges`` (int64 [n, 2] rows (offset, length <= 8192), both
     multiples of 4) of ``grads`` and (b) ``extra``: partial sums of squares the gradient kernels already wrote."""

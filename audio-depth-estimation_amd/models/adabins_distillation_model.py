@@ -132,8 +132,11 @@ class AdaBinsDistillationModel(nn.Module):
         return self._engine
 
     def forward_audio(self, audio):
-        """Student branch (reference :353-399): dict of NCHW f32 tensors (detached copies)."""
-        return self.engine().run_branch('audio', audio, self.training)
+        """Student branch (reference :353-399): dict of NCHW f32 tensors.  In training mode with autograd enabled the
+        tensors hang off one autograd node (adabins_engine._StudentFunction), so a loss built from them back-propagates
+        into the student's parameters; otherwise they are plain values."""
+        from ..adabins_engine import run_student
+        return run_student(self.engine(), audio, self.training)
 
     def forward_rgb(self, rgb):
         """Teacher branch (reference :301-351)."""
@@ -141,8 +144,9 @@ class AdaBinsDistillationModel(nn.Module):
 
     def forward(self, audio, rgb=None, mode='train'):
         """audio [B,2,H,W] (+ rgb [B,3,H,W] in training) -> {'audio': {...}, 'rgb': {...} | None} (reference :401-426).
-        The returned tensors are forward values; training goes through ``adabins_engine.AdaBinsTrainer`` (fused
-        DistillationLoss + backward + clip + AdamW), which replaces train_adabins_distillation.py:445-456."""
+        The reference's loop (criterion(outputs, gt, mask)[0].backward(); clip; optimizer.step()) works on the returned
+        tensors; ``adabins_engine.AdaBinsTrainer`` (fused DistillationLoss + backward + clip + AdamW) is the fast
+        replacement of train_adabins_distillation.py:445-456."""
         audio_output = self.forward_audio(audio)
         rgb_output = self.forward_rgb(rgb) if (mode == 'train' and rgb is not None) else None
         return {'audio': audio_output, 'rgb': rgb_output}

@@ -61,10 +61,11 @@ class BaseResidualDepthNet(nn.Module):
         return self._engine
 
     def forward(self, x):
-        """x [B, C, H, W] -> (base_depth, residual, final_depth), each [B, 1, H, W] f32 (forward values; training goes
-        through base_residual_engine.BaseResidualTrainer)."""
-        with torch.no_grad():
-            return self.engine().run(x, self.training)
+        """x [B, C, H, W] -> (base_depth, residual, final_depth), each [B, 1, H, W] f32.  In training mode under autograd
+        the three hang off one autograd node, so the reference's criterion(...).backward() loop works; the fused
+        base_residual_engine.BaseResidualTrainer is the fast path."""
+        from ..base_residual_engine import run_base_residual
+        return run_base_residual(self.engine(), x, self.training)
 
     def get_parameters_count(self):
         cnt = lambda mods: sum(p.numel() for m in mods for p in m.parameters())

@@ -104,6 +104,9 @@ int adn_version(void);   /* ABI revision of this header: 2 (round 2: AdnWgradDes
  * instead of values that depend on the previous kernel (the Python binding calls it in front of every launch when
  * ADN_LDS_POISON=1).  No counterpart in the reference. */
 int adn_debug_poison_lds(void* stream);
+/* Measurement aid (tools/overlap_experiment.py): dst += src over `bytes` on exactly `workgroups` workgroups, `passes` times --
+ * the local HBM traffic of a ring all-reduce kernel, to price the exchange beside the backward pass on one GPU. */
+int adn_debug_stream_rmw(const void* src, void* dst, int64_t bytes, int32_t workgroups, int32_t passes, void* stream);
 
 /* Number of stats partial rows P the implicit GEMM will write for this descriptor. */
 int64_t adn_igemm_num_partials(const AdnIgemmDesc* d);
@@ -492,6 +495,11 @@ int adn_thin_wgrad(const float* thin, int32_t ct_n, const void* plain0, int32_t 
 /* sum over n f32/dtype elements into one f32 (bias gradient of the outermost ConvTranspose2d). */
 int adn_sum_to_scalar(const void* x, int64_t n, int32_t dtype, float* out, void* workspace,
                       int64_t workspace_bytes, void* stream);
+
+/* Sums of squares of grads[0:n] as adn_grad_norm_workspace_bytes(n)/8 doubles (the first half of adn_grad_norm).  Used per
+ * all-reduce bucket by the data-parallel step (ddp.py; replaces the post-exchange norm pass of
+ * torch.nn.utils.clip_grad_norm_, train.py:267); finish with adn_grad_norm_ranges(extra = the collected slots). */
+int adn_grad_sqsum_partials(const float* grads, int64_t n, double* partials, int64_t partials_bytes, void* stream);
 
 /* Gradient clipping + optimizer (train.py:689-691: clip_grad_norm_(params, 1.0); optimizer.step()).
  * state (device, f64[8]): [0] step count, [1] bias_corr1, [2] bias_corr2, [3] total grad norm,

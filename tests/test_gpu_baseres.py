@@ -239,3 +239,51 @@ def test_output_size_resize_inside_the_decoders():
             continue
         got = eng.grad_view(named[k]).detach().double().cpu()
         assert float((got - want).norm() / want.norm()) <= 2e-2, k      # (ReLU flips)
+
+
+@pytest.mark.parametrize('variant', ['silog', 'l1', 'mse'])
+def test_reference_style_autograd_loop_matches_the_fused_trainer(variant):
+    """train_base_residual.py's loop as written -- base, res, final = model(x); loss, _ = criterion(base, res, final, gt,
+    gt > 0); loss.backward(); clip_grad_norm_; optimizer.step() -- on the mirror modules: the gradients that reach
+    .grad equal the fused trainer's (f32 compute: <= 1e-5 of each tensor's max), and two steps with torch.optim.AdamW
+    land within 0.25 * lr of the fused trainer's parameters."""
+    from audio_depth_estimation_amd.base_residual_engine import BaseResidualTrainer
+    from audio_depth_estimation_amd.models.base_residual_model import BaseResidualDepthNet
+    from audio_depth_estimation_amd.utils_base_residual_loss import BaseResidualLoss
+    g = torch.Generator().manual_seed(21)
+    x = torch.rand(2, 2, 32, 32, generator=g).to('cuda')
+    gt = (30 * torch.rand(2, 1, 32, 32, generator=g)).to('cuda')
+    gt[:, :, :4] = 0.0                                   # some invalid pixels
+    kw = dict(use_l1=variant == 'l1', use_silog=variant == 'silog')
+    lr = 1e-3
+
+    def make():
+        torch.manual_seed(3)
+        m = BaseResidualDepthNet(2, 64, True, 32, 30.0)
+        m.compute_dtype = torch.float32
+        return m.to('cuda').train()
+
+    ma, mb = make(), make()
+    crit = BaseResidualLoss(1.0, 1.2, 0.05, 16, **kw)
+    opt = torch.optim.AdamW(ma.parameters(), lr=lr)
+    tr = BaseResidualTrainer.from_criterion(mb.engine(), crit, lr=lr, clip_norm=1.0)
+    for it in range(2):
+        opt.zero_grad()
+        base, res, final = ma(x)
+        assert final.requires_grad and base.requires_grad
+        loss, parts = crit(base, res, final, gt, gt > 0)
+        loss.backward()
+        lt, terms = tr.step(x, gt)
+        assert abs(float(loss) - float(lt)) <= 1e-5 * abs(float(lt)), (it, float(loss), float(lt))
+        if it == 0:
+            for (k, p), (_, q) in zip(ma.named_parameters(), mb.named_parameters()):
+                gb = mb.engine().grad_view(q)
+                assert p.grad is not None, k
+                assert float((p.grad - gb).abs().max()) <= 1e-5 * float(gb.abs().max()) + 1e-12, k
+        torch.nn.utils.clip_grad_norm_(ma.parameters(), 1.0)
+        opt.step()
+    for (k, p), (_, q) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert float((p - q).abs().max()) <= 0.25 * lr, k
+    with torch.no_grad():                                 # no graph outside training / under no_grad
+        assert not ma(x)[2].requires_grad
+    assert not ma.eval()(x)[2].requires_grad
