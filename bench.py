@@ -194,6 +194,9 @@ def main():
     ap.add_argument('--no-f32', action='store_true', help='skip the exact-f32 sub-record (N=1 only)')
     ap.add_argument('--sustain-seconds', type=float, default=2.0,
                     help='length of the sustained per-step-event run behind the timed region (0 = skip)')
+    ap.add_argument('--ddp-payload', default='f32', choices=['f32', 'bf16'],
+                    help='what the gradient all-reduce carries (N > 1): f32 = DataParallel arithmetic (default), bf16 = half the bytes')
+    ap.add_argument('--bucket-mb', type=int, default=32, help='all-reduce bucket size (N > 1)')
     ap.add_argument('--cpu-batch', type=int, default=8)
     ap.add_argument('--cpu-steps', type=int, default=25)     # B=8: about 12 s of host work (bounded sample)
     args = ap.parse_args()
@@ -207,7 +210,7 @@ def main():
     device = torch.device('cuda', local % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(device)
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
-    reducer = addp.GradientAllReducer() if world > 1 else None
+    reducer = addp.GradientAllReducer(bucket_bytes=args.bucket_mb << 20, payload=args.ddp_payload) if world > 1 else None
     backend = dist.get_backend() if world > 1 else None
     model, trainer = build_trainer(dtype, device, reducer)
     B, S = args.batch, 256
@@ -284,7 +287,8 @@ def main():
                 continue
         par = f'dp{world}'
         if world > 1:
-            par += f' ({"RCCL" if backend == "nccl" else backend} bucketed gradient all-reduce, backend={backend})'
+            par += (f' ({"RCCL" if backend == "nccl" else backend} gradient all-reduce in {args.bucket_mb} MiB buckets beside '
+                    f'the backward, {args.ddp_payload} payload, backend={backend})')
         result = {
             'metric': 'depth-maps/sec (train step)', 'value': world * B * args.steps / elapsed,
             'unit': 'depth-maps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
