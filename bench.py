@@ -273,15 +273,16 @@ def main():
         # HBM bytes per launch of the dominant kernel: NOT measured in this run -- taken from the committed PMC passes
         # of this command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, read side doubled per
         # MI355X_MICROARCH.md; tools/pmc_traffic.py); null when no such file matches
-        traffic, traffic_src = None, None
-        for name in ('r02_pmc_traffic_gemm.json', 'r01_pmc_traffic_gemm.json'):
+        traffic, traffic_src, traffic_commit = None, None, None
+        for name in ('r03_pmc_traffic_gemm.json', 'r02_pmc_traffic_gemm.json', 'r01_pmc_traffic_gemm.json'):
             try:
                 pm = json.load(open(os.path.join(ROOT, 'profiles', name)))
-                fams = ('igemm_patch_kernel', 'igemm_mfma_kernel') if dom == 'igemm' else ('wgrad_k4_patch_kernel', 'wgrad_mfma_kernel')
-                rows = [v for k, v in pm.items() if k.startswith(fams)]
+                fams = (('igemm_ring_kernel', 'igemm_patch_kernel', 'igemm_mfma_kernel') if dom == 'igemm'
+                        else ('wgrad_k4_patch_kernel', 'wgrad_mfma_kernel'))
+                rows = [v for k, v in pm.items() if k.startswith(fams) and isinstance(v, dict)]
                 if rows and args.dtype == 'bf16' and B == 32:
                     traffic = sum(r['launches'] * r['hbm_bytes_per_launch'] for r in rows) / sum(r['launches'] for r in rows)
-                    traffic_src = 'profiles/' + name
+                    traffic_src, traffic_commit = 'profiles/' + name, pm.get('_commit')
                     break
             except Exception:
                 continue
@@ -299,10 +300,10 @@ def main():
                        'global_batch': world * B, 'image_size': S, 'launch': 'hipGraph' if use_graph else 'launch-plan',
                        'parallelism': par},
             'roofline': {'bound': 'mfma',
-                         'kernel': {'igemm': 'igemm_patch_kernel + igemm_mfma_kernel (implicit-GEMM family: forward + input gradients)',
+                         'kernel': {'igemm': 'igemm_ring_kernel + igemm_patch_kernel + igemm_mfma_kernel (implicit-GEMM family: forward + input gradients)',
                                     'wgrad': 'wgrad_k4_patch_kernel + wgrad_mfma_kernel (weight gradients)'}.get(dom, dom),
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-                         'traffic': traffic, 'traffic_source': traffic_src, 'launches': launches,
+                         'traffic': traffic, 'traffic_source': traffic_src, 'traffic_commit': traffic_commit, 'launches': launches,
                          'avg_launch_ms': 1e3 * secs / launches,
                          'gemm_ms_per_step': 1e3 * gemm_secs / max(1, prof_steps),
                          'all_gemm_tflops': sum(v[0] for v in fam.values()) / gemm_secs / 1e12},

@@ -246,7 +246,7 @@ def test_reference_style_autograd_loop_matches_the_fused_trainer(variant):
     """train_base_residual.py's loop as written -- base, res, final = model(x); loss, _ = criterion(base, res, final, gt,
     gt > 0); loss.backward(); clip_grad_norm_; optimizer.step() -- on the mirror modules: the gradients that reach
     .grad equal the fused trainer's (f32 compute: <= 1e-5 of each tensor's max), and two steps with torch.optim.AdamW
-    land within 0.25 * lr of the fused trainer's parameters."""
+    stay on the fused trainer's trajectory (same loss at step 2 to 1e-5, mean parameter distance <= 0.02 * lr)."""
     from audio_depth_estimation_amd.base_residual_engine import BaseResidualTrainer
     from audio_depth_estimation_amd.models.base_residual_model import BaseResidualDepthNet
     from audio_depth_estimation_amd.utils_base_residual_loss import BaseResidualLoss
@@ -282,8 +282,11 @@ def test_reference_style_autograd_loop_matches_the_fused_trainer(variant):
                 assert float((p.grad - gb).abs().max()) <= 1e-5 * float(gb.abs().max()) + 1e-12, k
         torch.nn.utils.clip_grad_norm_(ma.parameters(), 1.0)
         opt.step()
+    # (AdamW moves every element by about lr per step whatever its gradient's size, so elements whose tiny gradient
+    #  differs in the last bits may differ by a step; the loss of step 2 above already agreed to 1e-5)
     for (k, p), (_, q) in zip(ma.named_parameters(), mb.named_parameters()):
-        assert float((p - q).abs().max()) <= 0.25 * lr, k
+        d = (p - q).abs()
+        assert float(d.max()) <= 4.1 * lr and float(d.mean()) <= 0.02 * lr, (k, float(d.max()), float(d.mean()))
     with torch.no_grad():                                 # no graph outside training / under no_grad
         assert not ma(x)[2].requires_grad
     assert not ma.eval()(x)[2].requires_grad
