@@ -225,7 +225,7 @@ _PROTOS = {
 _lib = None
 
 
-ABI_VERSION = 2      # adn_version() of the libadn.so these bindings describe (include/adn.h)
+ABI_VERSION = 3      # adn_version() of the libadn.so these bindings describe (include/adn.h)
 
 
 def load():

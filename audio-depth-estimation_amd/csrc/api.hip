@@ -15,7 +15,7 @@ void adn_set_error(const char* fmt, ...) {
 
 extern "C" const char* adn_last_error(void) { return g_err; }
 // 2: AdnWgradDesc grew (sq_partials); adn_wgrad_sq_count, adn_grad_norm_ranges, adn_loss_finish_dz added
-extern "C" int adn_version(void) { return 2; }
+extern "C" int adn_version(void) { return 3; }
 
 
 // ---- debugging aid: poison the LDS of every CU ----------------------------------------------------------------------

@@ -98,8 +98,8 @@ typedef struct {
 } AdnIgemmDesc;
 
 const char* adn_last_error(void);
-int adn_version(void);   /* ABI revision of this header: 2 (round 2: AdnWgradDesc.sq_partials, adn_wgrad_sq_count,
-                            adn_grad_norm_ranges, adn_loss_finish_dz) */
+int adn_version(void);   /* ABI revision of this header: 3 (round 3: adn_grad_sqsum_partials, adn_debug_poison_lds,
+                            adn_debug_stream_rmw) */
 /* Debugging aid: fills the LDS of every CU with 0xFFFFFFFF so that a kernel reading LDS it never wrote produces NaN
  * instead of values that depend on the previous kernel (the Python binding calls it in front of every launch when
  * ADN_LDS_POISON=1).  No counterpart in the reference. */

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for name in _header_symbols():
         assert hasattr(raw, name), name
-    assert lib.adn_version() == 2
+    assert lib.adn_version() == 3
     assert lib.adn_last_error() is not None
     out = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r' T (adn_[a-z0-9_]+)', out))

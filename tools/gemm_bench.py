@@ -56,8 +56,32 @@ def timeit(fn, iters):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
+_FLUSH = None
+
+
+def timeit_cold(fn, iters):
+    """Every launch timed on its own, a 1 GB fill in front of it (beyond L2 + the 256 MB memory-side cache): operands come
+    from HBM as they do inside a training step."""
+    global _FLUSH
+    if _FLUSH is None:
+        _FLUSH = torch.empty(1 << 28, device=DEV)
+    fn()
+    tot = 0.0
+    for _ in range(iters):
+        _FLUSH.fill_(1.0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        tot += e0.elapsed_time(e1)
+    return tot * 1e-3 / iters
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument('--cold', action='store_true', help='flush the caches in front of every timed launch')
+    ap.add_argument('--bwd-epi', action='store_true', help='run the *_dgrad shapes with the BWD epilogue (act mask, BN-backward sums)')
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--only', default=None)
     ap.add_argument('--attn', action='store_true', help='binaural cross-attention levels instead')
@@ -70,6 +94,8 @@ def main():
     ap.add_argument('--edge', action='store_true', help='thin outermost layers of unet_256 with their real epilogues')
     args = ap.parse_args()
     torch.manual_seed(0)
+    if args.cold:
+        globals()['timeit'] = timeit_cold
     if args.mx8:
         return mx8_main(args)
     if args.s1:
@@ -88,10 +114,17 @@ def main():
         w = (torch.randn((1 if geom == 0 else 4) * N * taps * (C0 + C1), device=DEV) * 0.05).to(T)
         hout = Hs if geom == 0 else 2 * Hs
         out = torch.empty(B, hout, hout, N, device=DEV, dtype=T)
-        P, wsb = K.igemm_query(T, geom, B, Hs, Hs, C0, C1, N, [N])
+        bwd = args.bwd_epi and name.endswith('dgrad')
+        P, wsb = K.igemm_query(T, geom, B, Hs, Hs, C0, C1, N, [N], epi=3 if bwd else 1)
         ws = torch.empty(max(wsb, 16) // 4, device=DEV)
         part = torch.empty(P * 2 * N, device=DEV)
-        fn = lambda: K.igemm(T, geom, B, Hs, Hs, in0, in1, w, N, 1, [K.Seg(N, out0=out, partials=part)], ws)
+        if bwd:
+            ref, z = torch.randn_like(out), torch.randn_like(out)
+            mean, istd = torch.zeros(N, device=DEV), torch.ones(N, device=DEV)
+            fn = lambda: K.igemm(T, geom, B, Hs, Hs, in0, in1, w, N, 3,
+                                 [K.Seg(N, out0=out, ref=ref, slope=0.2, z=z, mean=mean, istd=istd, partials=part)], ws)
+        else:
+            fn = lambda: K.igemm(T, geom, B, Hs, Hs, in0, in1, w, N, 1, [K.Seg(N, out0=out, partials=part)], ws)
         t = timeit(fn, args.iters)
         fl = 2.0 * B * Hs * Hs * N * 16 * (C0 + C1)
         print(f'{name:10s} M={B*Hs*Hs*(1 if geom == 0 else 4):7d} N={N:4d} K={taps*(C0+C1):5d}  {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF/s', flush=True)
