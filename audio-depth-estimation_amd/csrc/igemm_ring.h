@@ -42,6 +42,61 @@ __device__ __forceinline__ float ring_row_sum(float v) {
   return ring_row_ror_add<1>(v);
 }
 
+// Reduce-scatter of per-lane values over the 16 lanes of a DPP row, four results per call.  Step A pairs lane L with 15 - L
+// (row_mirror: bit 3 differs), lanes 0-7 keep the sums of the `lo` values, lanes 8-15 those of the `hi` values (bank masks
+// 0x3 / 0xc: a disabled lane keeps its destination); step B pairs L with its mirror inside the half row (bit 2 differs,
+// bank masks 0x5 / 0xa).  One v_add_f32_dpp per kept value and step instead of v_mov_b32_dpp + add on every value: a row
+// total of V values per lane costs V + V/2 + 2 * V/4 instructions instead of 6 V.  (s_nop 1: a VALU result may not be read
+// by a DPP operand in the next two issue slots; the hazard recogniser does not look inside inline assembly.)
+__device__ __forceinline__ void ring_rs_mirror4(const float* lo, const float* hi, float* out) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %4, %4 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %1, %5, %5 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %2, %6, %6 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %3, %7, %7 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %0, %8, %8 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %1, %9, %9 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %2, %10, %10 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %3, %11, %11 row_mirror row_mask:0xf bank_mask:0xc"
+      : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3])
+      : "v"(lo[0]), "v"(lo[1]), "v"(lo[2]), "v"(lo[3]), "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]));
+}
+__device__ __forceinline__ void ring_rs_half_mirror4(const float* lo, const float* hi, float* out) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %4, %4 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %1, %5, %5 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %2, %6, %6 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %3, %7, %7 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %0, %8, %8 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %1, %9, %9 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %2, %10, %10 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %3, %11, %11 row_half_mirror row_mask:0xf bank_mask:0xa"
+      : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3])
+      : "v"(lo[0]), "v"(lo[1]), "v"(lo[2]), "v"(lo[3]), "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]));
+}
+// all-reduce over the four lanes of a quad (every lane ends with the quad total), four values per call
+__device__ __forceinline__ void ring_quad_sum4(float* v) {
+  float t[4];
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+      : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3])
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %5, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %6, %6 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %7, %7 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+      : "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]));
+}
+
 #ifdef ADN_RING_STAMPS
 // diagnostic build only (tools/ring_diag.py): s_memtime around the parts of a K-step, sums written to the workspace
 #define RING_STAMP(var)                                                                   \
@@ -420,35 +475,32 @@ __global__ __launch_bounds__(512, 2) void igemm_ring_kernel(KParams p, int ntile
         for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4_t*>(out + opix[i] + 32 * h) = pack8(i, h);
     }
     RING_STAMP(x1);
-    // column sums: over the 16 pixels of a DPP row by rotations (every lane ends with the row total), then over the four
-    // pixel-row waves that share these channels through LDS
+    // column sums over the 16 pixels of a DPP row as a reduce-scatter (see ring_rs_mirror4): the lanes of a row end with
+    // the totals of DIFFERENT values -- lanes 0-7 the sums (s1), lanes 8-15 the second statistic (s2); inside each half,
+    // lanes 0-3 the first and lanes 4-7 the second half of the channels -- then over the four pixel-row waves that share
+    // these channels through LDS
     if (any_stats) {
+      constexpr int HV = NH * 8;           // values per statistic and lane
+      constexpr int QV = HV / 2;           // values a lane keeps
+      float kept[QV];
+      if constexpr (STATS) {
+        float half[HV];
 #pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        if constexpr (STATS) {
+        for (int k = 0; k < HV; k += 4) ring_rs_mirror4(&s1[0][0] + k, &s2[0][0] + k, half + k);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            s1[h][e] = ring_row_sum(s1[h][e]);
-            s2[h][e] = ring_row_sum(s2[h][e]);
-          }
-          if constexpr (BWD) {
-            const f32x4_t m0 = *reinterpret_cast<const f32x4_t*>(sg.mean + nl0 + 32 * h), m1 = *reinterpret_cast<const f32x4_t*>(sg.mean + nl0 + 32 * h + 4);
-            const f32x4_t i0 = *reinterpret_cast<const f32x4_t*>(sg.istd + nl0 + 32 * h), i1 = *reinterpret_cast<const f32x4_t*>(sg.istd + nl0 + 32 * h + 4);
+        for (int k = 0; k < QV; k += 4) ring_rs_half_mirror4(half + k, half + QV + k, kept + k);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              s2[h][e] = (s2[h][e] - m0[e] * s1[h][e]) * i0[e];
-              s2[h][4 + e] = (s2[h][4 + e] - m1[e] * s1[h][4 + e]) * i1[e];
-            }
-          }
-        }
-        if (frow == 0) {
-          float* r1 = red + (wave * 2 + 0) * (BN / 2) + 32 * h + 8 * fq;
-          float* r2 = red + (wave * 2 + 1) * (BN / 2) + 32 * h + 8 * fq;
-          *reinterpret_cast<f32x4_t*>(r1) = f32x4_t{s1[h][0], s1[h][1], s1[h][2], s1[h][3]};
-          *reinterpret_cast<f32x4_t*>(r1 + 4) = f32x4_t{s1[h][4], s1[h][5], s1[h][6], s1[h][7]};
-          *reinterpret_cast<f32x4_t*>(r2) = f32x4_t{s2[h][0], s2[h][1], s2[h][2], s2[h][3]};
-          *reinterpret_cast<f32x4_t*>(r2 + 4) = f32x4_t{s2[h][4], s2[h][5], s2[h][6], s2[h][7]};
-        }
+        for (int k = 0; k < QV; k += 4) ring_quad_sum4(kept + k);
+      } else {
+#pragma unroll
+        for (int k = 0; k < QV; ++k) kept[k] = 0.f;
+      }
+      if ((frow & 3) == 0) {
+        const int st = frow >> 3, q = (frow >> 2) & 1;
+        // NH = 2: the kept values are channels 32 q + 8 fq + 0..7 of this wave; NH = 1: channels 8 fq + 4 q + 0..3
+        float* r = red + (wave * 2 + st) * (BN / 2) + (NH == 2 ? 32 * q + 8 * fq : 8 * fq + 4 * q);
+#pragma unroll
+        for (int k = 0; k < QV; k += 4) *reinterpret_cast<f32x4_t*>(r + k) = f32x4_t{kept[k], kept[k + 1], kept[k + 2], kept[k + 3]};
       }
       RING_STAMP(x2);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (not __syncthreads(): its vmcnt(0) would drain the ring)
@@ -465,6 +517,14 @@ __global__ __launch_bounds__(512, 2) void igemm_ring_kernel(KParams p, int ntile
         const AdnEpiSeg& sq = (n < p.seg[0].channels) ? p.seg[0] : p.seg[1];
         const int ncl = (n < p.seg[0].channels) ? n : n - p.seg[0].channels;
         const int64_t P = (int64_t)t.phase * p.tiles_m + t.tile_m;
+        if constexpr (BWD) {       // second statistic of the backward epilogue: (sum g z - mean sum g) * istd
+          if (st == 1 && sq.partials) {
+            float tg = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) tg += red[((w * 2 + cw) * 2 + 0) * (BN / 2) + cc];
+            tot = (tot - sq.mean[ncl] * tg) * sq.istd[ncl];
+          }
+        }
         if (sq.partials) sq.partials[(P * 2 + st) * sq.channels + ncl] = tot;
       }
 #ifdef ADN_RING_STAMPS

@@ -13,3 +13,8 @@ python tools/gemm_bench.py > gpurun_out/r3/final/gemm_microbench.txt 2>&1
 python tools/gemm_bench.py --s1 > gpurun_out/r3/final/s1_gemm_microbench.txt 2>&1
 python tools/gemm_bench.py --mx8 > gpurun_out/r3/final/mx8_microbench.txt 2>&1
 ls gpurun_out/r3/final
+python tools/gemm_bench.py --deep > gpurun_out/r3/final/deep_microbench.txt 2>&1
+python tools/gemm_bench.py --bwd-epi > gpurun_out/r3/final/gemm_bwd_hot.txt 2>&1
+python tools/gemm_bench.py --bwd-epi --cold > gpurun_out/r3/final/gemm_bwd_cold.txt 2>&1
+python tools/step_timeline.py > gpurun_out/r3/final/step_timeline.txt 2>&1
+ls gpurun_out/r3/final
