@@ -156,6 +156,7 @@ _PROTOS = {
     'adn_featcos_grad': (C.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p]),
     'adn_distill_small': (C.c_int, [C.POINTER(AdnDistillSmall), c_void_p]),
     'adn_resize_nearest': (C.c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    'adn_resize_nearest_bwd': (C.c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     'adn_image_prepare': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     'adn_depth_prepare': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_void_p,
                                     c_void_p]),

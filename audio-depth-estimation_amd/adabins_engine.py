@@ -393,9 +393,6 @@ class _StudentFunction(torch.autograd.Function):
     def forward(ctx, audio, engine, *params):
         eng = engine
         eng._prepare_branches(audio.shape[0], audio.shape[2], audio.shape[3], audio.device)
-        if eng.resize_to is not None:
-            raise NotImplementedError('autograd through AdaBinsDistillationModel needs output_size == input size '
-                                      '(call under torch.no_grad() for the forward values)')
         br = eng.branches['audio']
         eng._forward_branch(br, audio, True)
         eng._finalize_plain(br)
@@ -414,7 +411,12 @@ class _StudentFunction(torch.autograd.Function):
         if ctx.stamp != eng.autograd_pass:
             raise RuntimeError('AdaBinsDistillationModel: backward through a forward whose activations were overwritten '
                                'by a later training forward of the same module')
-        _backward_leaves(eng, g[0:5], g[5], g[7], g[8], g[9], g[10])
+        g_logits, g_base, g_res, g_final = g[7], g[8], g[9], g[10]
+        if eng.resize_to is not None:          # the returned maps are nearest-resized: gradients back through the gather
+            H, W = eng.branches['audio'].logits.H, eng.branches['audio'].logits.W
+            back = lambda t: None if t is None else K.resize_nearest_bwd(t.contiguous().float(), H, W)
+            g_logits, g_base, g_res, g_final = back(g_logits), back(g_base), back(g_res), back(g_final)
+        _backward_leaves(eng, g[0:5], g[5], g_logits, g_base, g_res, g_final)
         off = eng.train_offset
         return (None, None) + tuple(eng.grad_view(p) if (o >= off and p.requires_grad) else None
                                     for p, o, _ in eng.param_meta)
@@ -503,6 +505,19 @@ class AdaBinsTrainer(GraphedStep):
                 self.bucket_norm = self.ddp.enable_bucket_norm()
         self._ready = True
 
+    def _mean_logits_resized(self, br, S):
+        """Spatial mean of the nearest-resized bin logits (the KL term's input when output_size != input size)."""
+        eng, lg = self.engine, br.logits
+        B = eng.B
+        f32 = dict(dtype=torch.float32, device=lg.data.device)
+        t = torch.empty(B, lg.C, lg.H, lg.W, **f32)
+        K.nhwc_to_nchw(lg.data, t)
+        r = K.resize_nearest(t, S)
+        n = torch.empty(B, S, S, lg.C, **f32)
+        K.nchw_to_nhwc(r, n)
+        wsp = torch.empty(max(K.pool_workspace_bytes(B, S * S, lg.C, 1), 16) // 4, **f32)
+        K.pool(n, None, B, S * S, lg.C, 1, 1.0 / (S * S), br.mean_logits, wsp)
+
     def enable_graph(self, after_steps=3):
         if self.ddp is not None:
             raise RuntimeError('the hipGraph step is not combined with the data-parallel reducer (host-side collectives)')
@@ -550,9 +565,6 @@ class AdaBinsTrainer(GraphedStep):
         eng = self.engine
         m = eng.module
         eng._prepare_branches(audio.shape[0], audio.shape[2], audio.shape[3], audio.device)
-        if eng.resize_to is not None:
-            raise NotImplementedError(f'AdaBinsTrainer: input {audio.shape[2]}x{audio.shape[3]} != output_size {m.output_size}; the '
-                                      'fused distillation step is built for output_size == input size (forward() supports both)')
         if not self._ready:
             self._setup(audio.device)
         st, te = eng.branches['audio'], eng.branches['rgb']
@@ -563,8 +575,25 @@ class AdaBinsTrainer(GraphedStep):
             eng._finalize_plain(te)
         eng._forward_branch(st, audio, True)
         lt, lr_, lf, lb, ls = self.lambdas
-        K.distill_pix_stats(st.base, st.head.result, gt, te.final if has_t else None, m.max_depth, st.final,
-                            eng.pix_stats, eng.workspace)
+        # output_size != input size: the reference resizes logits and residual with mode='nearest' before the per-pixel maps
+        # (:196-198, 334-337, 383-386).  Those maps commute with a nearest resize, so the outputs at S x S are gathers of the
+        # input-resolution ones: the pixel terms are evaluated on the gathered base / residual against the S x S target, the
+        # mean logits over the gathered logits, and the gradients come back through the gather's transpose
+        # (adn_resize_nearest_bwd) before the student's backward.  Plain tensors per step: the rare path is not tuned.
+        S = eng.resize_to
+        B, H, W = eng.B, st.logits.H, st.logits.W
+        f32 = dict(dtype=torch.float32, device=gt.device)
+        if S is None:
+            base_o, res_o, tfin_o, final_o = st.base, st.head.result, (te.final if has_t else None), st.final
+        else:
+            shp = (B, 1, H, W)
+            base_o = K.resize_nearest(st.base.view(shp), S).view(-1)
+            res_o = K.resize_nearest(st.head.result.view(shp), S).view(-1)
+            tfin_o = K.resize_nearest(te.final, S).view(-1) if has_t else None
+            final_o = torch.empty(B, 1, S, S, **f32)
+            if gt.shape[-2:] != (S, S):
+                raise RuntimeError(f'AdaBinsTrainer: gt is {tuple(gt.shape)}, the model output is {S}x{S}')
+        K.distill_pix_stats(base_o, res_o, gt, tfin_o, m.max_depth, final_o, eng.pix_stats, eng.workspace)
         world = 1
         if self.ddp is not None:
             # DataParallel computes ONE loss on the gathered outputs (adabins_distillation_model.py:493-496): the pixel
@@ -572,10 +601,16 @@ class AdaBinsTrainer(GraphedStep):
             # world x B samples (their weights / world here, gradients SUM-reduced below)
             world = self.ddp.world_size
             self.ddp.all_reduce_loss_stats(eng.pix_stats)
-        B, HW = eng.B, st.logits.H * st.logits.W
-        K.pool(st.logits.data, None, B, HW, m.n_bins, 1, 1.0 / HW, st.mean_logits, eng.workspace)
+        HW = H * W
+        if S is None:
+            K.pool(st.logits.data, None, B, HW, m.n_bins, 1, 1.0 / HW, st.mean_logits, eng.workspace)
+        else:
+            self._mean_logits_resized(st, S)
         if has_t:
-            K.pool(te.logits.data, None, B, HW, m.n_bins, 1, 1.0 / HW, te.mean_logits, eng.workspace)
+            if S is None:
+                K.pool(te.logits.data, None, B, HW, m.n_bins, 1, 1.0 / HW, te.mean_logits, eng.workspace)
+            else:
+                self._mean_logits_resized(te, S)
             for i, (a, r) in enumerate(zip(st.feats, te.feats)):
                 K.pool(a.data, r.data, B, a.H * a.W, a.C, 3, 1.0, eng.feat_stats_buf[i], eng.workspace)
             eng.feat_stats = eng.feat_stats_buf
@@ -592,9 +627,26 @@ class AdaBinsTrainer(GraphedStep):
             eng.terms[6] = (lt * eng.terms[0] + lr_ * eng.terms[1] + lf * eng.terms[2] + lb * (eng.terms[3] + eng.terms[4])
                             + ls * eng.terms[5])
             self.ddp.begin_backward()
-        K.distill_pix_grad(st.base, st.head.result, gt, te.final if has_t else None, m.max_depth, eng.pix_stats, lt,
-                           lr_ if has_t else 0.0, ls, st.dbase, st.dres)
-        eng.backward_student(st.dbase, st.dres, st.dmean, st.dcent_extra)
+        if S is None:
+            K.distill_pix_grad(st.base, st.head.result, gt, tfin_o, m.max_depth, eng.pix_stats, lt,
+                               lr_ if has_t else 0.0, ls, st.dbase, st.dres)
+            eng.backward_student(st.dbase, st.dres, st.dmean, st.dcent_extra)
+        else:
+            db_o, dr_o = torch.empty(B * S * S, **f32), torch.empty(B * S * S, **f32)
+            K.distill_pix_grad(base_o, res_o, gt, tfin_o, m.max_depth, eng.pix_stats, lt, lr_ if has_t else 0.0, ls, db_o,
+                               dr_o)
+            dbase = K.resize_nearest_bwd(db_o.view(B, 1, S, S), H, W).view(-1)
+            dres = K.resize_nearest_bwd(dr_o.view(B, 1, S, S), H, W).view(-1)
+            # d KL / d logits: dmean / S^2 on every output pixel, back through the gather
+            gl = torch.empty(B, S, S, m.n_bins, **f32)
+            K.bcast_add(gl, st.dmean, 1.0 / (S * S), accumulate=False)
+            gn = torch.empty(B, m.n_bins, S, S, **f32)
+            K.nhwc_to_nchw(gl, gn)
+            gh = K.resize_nearest_bwd(gn, H, W)
+            glog = torch.empty(B, H, W, m.n_bins, **f32)
+            K.nchw_to_nhwc(gh, glog)
+            st.dmean.zero_()
+            eng.backward_student(dbase, dres, st.dmean, st.dcent_extra, logits_extra=glog)
         if self.ddp is not None:
             self.ddp.finish()
         off = eng.train_offset

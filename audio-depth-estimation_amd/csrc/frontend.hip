@@ -431,12 +431,53 @@ __global__ __launch_bounds__(256) void resize_nearest_kernel(const float* src, i
   }
 }
 
+// Backward of the above as a gather: gsrc[pl][iy][ix] = sum of gout over the output pixels whose source index is (iy, ix)
+// (the same index rule, evaluated on a candidate window around iy / scale; no atomics).
+__global__ __launch_bounds__(256) void resize_nearest_bwd_kernel(const float* gout, int64_t planes, int H, int W, int So,
+                                                                 float* gsrc) {
+  const int64_t n = planes * H * W;
+  const float sy = (float)H / So, sx = (float)W / So;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const int ix = (int)(e % W), iy = (int)((e / W) % H);
+    const int64_t pl = e / ((int64_t)H * W);
+    int y0 = (int)floorf(iy / sy) - 1, y1 = (int)floorf((iy + 1) / sy) + 1;
+    int x0 = (int)floorf(ix / sx) - 1, x1 = (int)floorf((ix + 1) / sx) + 1;
+    y0 = y0 < 0 ? 0 : y0;
+    x0 = x0 < 0 ? 0 : x0;
+    y1 = y1 > So - 1 ? So - 1 : y1;
+    x1 = x1 > So - 1 ? So - 1 : x1;
+    float acc = 0.f;
+    for (int y = y0; y <= y1; ++y) {
+      int ty = (int)floorf(y * sy);
+      ty = ty < H - 1 ? ty : H - 1;
+      if (ty != iy) continue;
+      for (int x = x0; x <= x1; ++x) {
+        int tx = (int)floorf(x * sx);
+        tx = tx < W - 1 ? tx : W - 1;
+        if (tx == ix) acc += gout[(pl * So + y) * So + x];
+      }
+    }
+    gsrc[e] = acc;
+  }
+}
+
 extern "C" int adn_resize_nearest(const float* src, int64_t planes, int32_t H, int32_t W, int32_t S, float* out, void* stream) {
   ADN_CHECK_ARG(src && out && planes > 0 && H > 0 && W > 0 && S > 0, "adn_resize_nearest: bad arguments");
   int64_t blocks = adn_cdiv(planes * S * S, 256);
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(resize_nearest_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src,
                      planes, H, W, S, out);
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
+}
+
+extern "C" int adn_resize_nearest_bwd(const float* gout, int64_t planes, int32_t H, int32_t W, int32_t S, float* gsrc,
+                                      void* stream) {
+  ADN_CHECK_ARG(gout && gsrc && planes > 0 && H > 0 && W > 0 && S > 0, "adn_resize_nearest_bwd: bad arguments");
+  int64_t blocks = adn_cdiv(planes * H * W, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(resize_nearest_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     gout, planes, H, W, S, gsrc);
   ADN_CHECK_LAUNCH();
   return ADN_OK;
 }

@@ -838,6 +838,17 @@ def resize_nearest(src, S):
     return out
 
 
+def resize_nearest_bwd(gout, H, W):
+    """gout f32 [..., S, S] -> gradient of the nearest-resized source, new tensor [..., H, W]."""
+    _dev(gout)
+    gout = gout.contiguous()
+    S = gout.shape[-1]
+    out = torch.empty(gout.shape[:-2] + (H, W), dtype=torch.float32, device=gout.device)
+    planes = gout.numel() // (S * S)
+    _lib.call('adn_resize_nearest_bwd', ptr(gout), planes, H, W, S, ptr(out), _stream())
+    return out
+
+
 def image_prepare(src, S, out):
     """src uint8 [B,H,W,3] BGR (decoded camera frames) -> out f32 [B,3,S,S] RGB in [0,1] (cv2 INTER_LINEAR resize)."""
     _dev(src, out)

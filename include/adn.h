@@ -566,6 +566,9 @@ int adn_image_prepare(const void* src_bgr_u8, int32_t B, int32_t H, int32_t W, i
  * AdaBins model's logits / residual when output_size != input size (adabins_distillation_model.py:196-198, 334-337, 383-386;
  * softmax expectation, tanh and clamp are per-pixel, so resizing their results is the same as resizing their inputs). */
 int adn_resize_nearest(const float* src, int64_t planes, int32_t H, int32_t W, int32_t S, float* out, void* stream);
+/* Its backward (the AdaBins distillation step when output_size != input size): gsrc [planes][H][W] <- sum of gout
+ * [planes][S][S] over the output pixels that read each source pixel. */
+int adn_resize_nearest_bwd(const float* gout, int64_t planes, int32_t H, int32_t W, int32_t S, float* gsrc, void* stream);
 /* transforms.Resize((S,S)) alone (utils_dataset.py:18-20): src f32 [planes][H][W] -> out [planes][S][S]. */
 int adn_resize_bilinear(const float* src, int32_t planes, int32_t H, int32_t W, int32_t S,
                         int32_t antialias, float* out, void* stream);
