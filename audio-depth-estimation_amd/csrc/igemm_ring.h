@@ -369,7 +369,7 @@ __global__ __launch_bounds__(512, 2) void igemm_ring_kernel(KParams p, int ntile
   // The data-dependent options (bias, accumulate, BatchNorm sums) are compile-time flags of the body: tested per element
   // they became a branch around every single load, and the loads of an absent bias made the Z_STATS path wait vmcnt(0)
   // -- i.e. for the whole staging ring -- before its first store.
-  auto epilogue_body = [&](int k, auto BWD_, auto FLAG_A, auto FLAG_S) {
+  auto epilogue_body = [&](int k, auto BWD_, auto FLAG_A, auto FLAG_S, auto FLAG_Z) {
     constexpr bool BWD = decltype(BWD_)::value;
     constexpr bool FA = decltype(FLAG_A)::value;       // Z_STATS: the conv has a bias;  BWD: accumulate into the output
     constexpr bool STATS = decltype(FLAG_S)::value;    // this wave's segment takes BatchNorm sums
@@ -440,12 +440,32 @@ __global__ __launch_bounds__(512, 2) void igemm_ring_kernel(KParams p, int ntile
       const uint16_t* ref = reinterpret_cast<const uint16_t*>(sg.ref);
       const uint16_t* zz = reinterpret_cast<const uint16_t*>(sg.z);
       const float slope = sg.slope;
+      // A segment with BatchNorm sums reads its pre-activation z anyway; when the caller also passes the forward's
+      // scale / shift, the activation's sign is that of fma(z, scale, shift) -- the very value the forward's apply kernel
+      // rounded to `ref` -- and `ref` is not read at all (a third of the operand traffic of an input-gradient launch that
+      // is HBM-bound at the wide levels).
+      constexpr bool MZ = STATS && decltype(FLAG_Z)::value;
       u32x4_t rr[2][NH], oo[2][NH], zr[2][NH];
+      [[maybe_unused]] float msc[NH][8], msh[NH][8];
+      if constexpr (MZ) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+          const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(sg.scale + nl0 + 32 * h), a1 = *reinterpret_cast<const f32x4_t*>(sg.scale + nl0 + 32 * h + 4);
+          const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(sg.shift + nl0 + 32 * h), b1 = *reinterpret_cast<const f32x4_t*>(sg.shift + nl0 + 32 * h + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            msc[h][e] = a0[e];
+            msc[h][4 + e] = a1[e];
+            msh[h][e] = b0[e];
+            msh[h][4 + e] = b1[e];
+          }
+        }
+      }
       auto request = [&](int i, u32x4_t* r_, u32x4_t* o_, u32x4_t* z_) {
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
           const unsigned idx = opix[i] + 32 * h;
-          r_[h] = *reinterpret_cast<const u32x4_t*>(ref + idx);
+          if constexpr (!MZ) r_[h] = *reinterpret_cast<const u32x4_t*>(ref + idx);
           if constexpr (FA) o_[h] = *reinterpret_cast<const u32x4_t*>(out + idx);
           if constexpr (STATS) z_[h] = *reinterpret_cast<const u32x4_t*>(zz + idx);
         }
@@ -459,12 +479,16 @@ __global__ __launch_bounds__(512, 2) void igemm_ring_kernel(KParams p, int ntile
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const uint32_t sh = (e & 1) ? 0u : 16u;
-            const float rf = __uint_as_float((rr[i & 1][h][e >> 1] << sh) & 0xffff0000u);
+            [[maybe_unused]] float zf = 0.f;
+            if constexpr (STATS) zf = __uint_as_float((zr[i & 1][h][e >> 1] << sh) & 0xffff0000u);
+            float rf;
+            if constexpr (MZ) rf = __builtin_fmaf(zf, msc[h][e], msh[h][e]);
+            else rf = __uint_as_float((rr[i & 1][h][e >> 1] << sh) & 0xffff0000u);
             float g = acc[i][2 * h + (e >> 2)][e & 3] * (rf > 0.f ? 1.0f : slope);
             if constexpr (FA) g += __uint_as_float((oo[i & 1][h][e >> 1] << sh) & 0xffff0000u);
             if constexpr (STATS) {       // s2 = sum g * z here; (sum g z - mean sum g) * istd once per channel below
               s1[h][e] += g;
-              s2[h][e] += g * __uint_as_float((zr[i & 1][h][e >> 1] << sh) & 0xffff0000u);
+              s2[h][e] += g * zf;
             }
             acc[i][2 * h + (e >> 2)][e & 3] = g;
           }
@@ -545,20 +569,23 @@ __global__ __launch_bounds__(512, 2) void igemm_ring_kernel(KParams p, int ntile
     if (p.epi == ADN_EPI_Z_STATS) {
       const bool bias = sg.bias != nullptr;
       if (bias) {
-        if (stats) epilogue_body(k, F_{}, T_{}, T_{});
-        else epilogue_body(k, F_{}, T_{}, F_{});
+        if (stats) epilogue_body(k, F_{}, T_{}, T_{}, F_{});
+        else epilogue_body(k, F_{}, T_{}, F_{}, F_{});
       } else {
-        if (stats) epilogue_body(k, F_{}, F_{}, T_{});
-        else epilogue_body(k, F_{}, F_{}, F_{});
+        if (stats) epilogue_body(k, F_{}, F_{}, T_{}, F_{});
+        else epilogue_body(k, F_{}, F_{}, F_{}, F_{});
       }
     } else {
       const bool accu = sg.accumulate != 0;
+      const bool zmask = stats && sg.scale != nullptr && sg.shift != nullptr;      // activation mask from z (no `ref` read)
       if (accu) {
-        if (stats) epilogue_body(k, T_{}, T_{}, T_{});
-        else epilogue_body(k, T_{}, T_{}, F_{});
+        if (zmask) epilogue_body(k, T_{}, T_{}, T_{}, T_{});
+        else if (stats) epilogue_body(k, T_{}, T_{}, T_{}, F_{});
+        else epilogue_body(k, T_{}, T_{}, F_{}, F_{});
       } else {
-        if (stats) epilogue_body(k, T_{}, F_{}, T_{});
-        else epilogue_body(k, T_{}, F_{}, F_{});
+        if (zmask) epilogue_body(k, T_{}, F_{}, T_{}, T_{});
+        else if (stats) epilogue_body(k, T_{}, F_{}, T_{}, F_{});
+        else epilogue_body(k, T_{}, F_{}, F_{}, F_{});
       }
     }
   };

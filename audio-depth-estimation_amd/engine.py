@@ -387,7 +387,8 @@ class UNetEngine(FlatParamEngine):
             if i < n - 1:
                 nx = L[i + 1]
                 segs.append(K.Seg(nx['cu_out'], out0=nx['Gu'], ref=nx['ru'], slope=0.0, z=nx['zu'],
-                                  mean=nx['mean_u'], istd=nx['istd_u'], partials=nx['bpart_u']))
+                                  mean=nx['mean_u'], istd=nx['istd_u'], partials=nx['bpart_u'],
+                                  scale=nx['scale_u'], shift=nx['shift_u']))
             if i == 0 and self.edge_path:
                 K.thin_wgrad(dz, in0, in1, B, hs, wsz, self._flat_slice(self.flat_g, lv['up'].weight), ws)
                 self._ready(lv['up'].weight)
@@ -420,7 +421,8 @@ class UNetEngine(FlatParamEngine):
                 seg = K.Seg(pv['cd_out'], out0=pv['Gd'], ref=pv['ad'], slope=LEAKY, accumulate=True)
                 if pv['bn_d'] is not None:
                     seg = K.Seg(pv['cd_out'], out0=pv['Gd'], ref=pv['ad'], slope=LEAKY, accumulate=True,
-                                z=pv['zd'], mean=pv['mean_d'], istd=pv['istd_d'], partials=pv['bpart_d'])
+                                z=pv['zd'], mean=pv['mean_d'], istd=pv['istd_d'], partials=pv['bpart_d'],
+                                scale=pv['scale_d'], shift=pv['shift_d'])
                 K.igemm(T, GEMM_T2, B, hs, wsz, lv['Gd'], None, lv['down_t2'], lv['cd_in'], EPI_BWD, [seg], ws)
         if self.on_grad_ready is not None:
             _lib.record_py(lambda: self.on_grad_ready(0))

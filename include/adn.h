@@ -69,8 +69,10 @@ typedef struct {
   const void* z;      /* ADN_EPI_BWD stats: raw forward conv output                              */
   const float* mean;  /* ADN_EPI_BWD stats                                                       */
   const float* istd;  /* ADN_EPI_BWD stats                                                       */
-  const float* scale; /* ADN_EPI_ACT: per-channel scale or NULL (=1)                             */
-  const float* shift; /* ADN_EPI_ACT: per-channel shift or NULL (=0)                             */
+  const float* scale; /* ADN_EPI_ACT: per-channel scale or NULL (=1).  ADN_EPI_BWD with stats, optional: the scale /
+                         shift the forward applied to z (ref = act(z * scale + shift)); a kernel may then take the
+                         mask from z and not read ref (the ring kernel does: one operand stream less)              */
+  const float* shift; /* ADN_EPI_ACT: per-channel shift or NULL (=0); ADN_EPI_BWD: see scale                      */
   const float* bias;  /* ADN_EPI_ACT / ADN_EPI_FINAL: per-channel bias or NULL                   */
   float* partials;    /* stats partial sums [P][2][channels] or NULL (no stats)                  */
   int32_t channels;   /* channels in this segment                                                */

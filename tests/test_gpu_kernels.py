@@ -50,8 +50,8 @@ def pack(w_xy44, dtype):
     return s2, t2
 
 
-def ws_for(dtype, geom, B, Hs, Ws, C0, C1, N, segs):
-    P, nbytes = K().igemm_query(dtype, geom, B, Hs, Ws, C0, C1, N, segs)
+def ws_for(dtype, geom, B, Hs, Ws, C0, C1, N, segs, epi=0):
+    P, nbytes = K().igemm_query(dtype, geom, B, Hs, Ws, C0, C1, N, segs, epi=epi)
     ws = torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=DEV)
     return P, ws
 
@@ -338,6 +338,48 @@ def test_epilogue_bwd_two_segments(dtype, shape):
     k.igemm(dtype, 1, B, Hs // 2, Hs // 2, nhwc(dzs, dtype), None, t2, Chalf, 3,
             [k.Seg(Chalf, out0=g0, ref=nhwc(ref_act[0], dtype), slope=0.2, accumulate=True)], ws2)
     assert rel_err(from_nhwc(g0), acc_ref) <= 2 * TOL_T_OUT[dtype]
+
+
+@pytest.mark.parametrize('accumulate', [False, True])
+@pytest.mark.parametrize('geom,shape', [(0, (16, 128, 128, 64)), (0, (32, 64, 256, 64)), (1, (16, 256, 128, 16)),
+                                        (1, (8, 128, 64, 32)), (0, (2, 128, 128, 8))])
+def test_epilogue_bwd_mask_from_z(geom, shape, accumulate):
+    """BWD epilogue with the forward's scale / shift passed along (bf16): ref = act(z * scale + shift) as the forward's
+    apply kernel writes it, so a kernel may take the mask from z and skip ref -- the ring kernel does (first four
+    shapes; the last runs the split-K path, which reads ref).  Gradient and both BatchNorm sums against torch."""
+    dtype = torch.bfloat16
+    B, Cz, N, Hs = shape                 # gradient channels in, channels out, small-grid size
+    torch.manual_seed(13)
+    k = K()
+    if geom == 0:                        # dgrad of a transposed conv (S2 geometry): out on the small grid
+        wt = rounded(torch.randn(N, Cz, 4, 4) * 0.1, dtype)
+        dz = rounded(torch.randn(B, Cz, 2 * Hs, 2 * Hs), dtype)
+        dA = F.conv2d(dz, wt, stride=2, padding=1)
+        w_op, Ho = pack(wt, dtype)[0], Hs
+    else:                                # dgrad of a conv (T2 geometry): out on the large grid
+        wt = rounded(torch.randn(Cz, N, 4, 4) * 0.1, dtype)
+        dz = rounded(torch.randn(B, Cz, Hs, Hs), dtype)
+        dA = F.conv_transpose2d(dz, wt, stride=2, padding=1)
+        w_op, Ho = pack(wt, dtype)[1], 2 * Hs
+    zfwd = rounded(torch.randn(B, N, Ho, Ho), dtype)
+    scale, shift = torch.randn(N) * 0.5 + 1.0, torch.randn(N) * 0.3
+    scale[::7] *= -1.0                                                    # (a negative gamma flips the mask)
+    slope = 0.2
+    act = torch.addcmul(shift.view(1, -1, 1, 1), zfwd, scale.view(1, -1, 1, 1))
+    ref_act = rounded(F.leaky_relu(act, slope), dtype)
+    mean, istd = torch.randn(N) * 0.1, torch.rand(N) + 0.5
+    old = rounded(torch.randn(B, N, Ho, Ho), dtype)
+    g_ref = dA * torch.where(act > 0, 1.0, slope) + (old if accumulate else 0.0)
+    xhat = (zfwd - mean.view(1, -1, 1, 1)) * istd.view(1, -1, 1, 1)
+    P, ws = ws_for(dtype, geom, B, Hs, Hs, Cz, 0, N, [N], epi=3)
+    out = nhwc(old, dtype).clone()
+    partials = torch.zeros(P, 2, N, dtype=torch.float32, device=DEV)
+    seg = k.Seg(N, out0=out, ref=nhwc(ref_act, dtype), z=nhwc(zfwd, dtype), mean=mean.to(DEV), istd=istd.to(DEV),
+                partials=partials, slope=slope, accumulate=accumulate, scale=scale.to(DEV), shift=shift.to(DEV))
+    k.igemm(dtype, geom, B, Hs, Hs, nhwc(dz, dtype), None, w_op, N, 3, [seg], ws)
+    assert rel_err(from_nhwc(out), g_ref) <= 2 * TOL_T_OUT[dtype]
+    assert rel_err(partials[:, 0].sum(0), g_ref.sum((0, 2, 3))) <= 2e-3
+    assert rel_err(partials[:, 1].sum(0), (g_ref * xhat).sum((0, 2, 3))) <= 2e-3
 
 
 @pytest.mark.parametrize('shape', [(8, 64, 64, 128, 32),      # ring kernel T2, 64-column tiles, two gathered sources
