@@ -145,7 +145,7 @@ def test_l0_forward_kernel(shape):
 
 
 @pytest.mark.parametrize('shape', [(2, 16, 32), (3, 8, 16), (1, 64, 64)])
-@pytest.mark.parametrize('stats', [True, False])
+@pytest.mark.parametrize('stats', [True, False, 'zmask'])
 def test_d0_dgrad_kernel(shape, stats):
     """Input gradient of the last transposed conv 128 -> 1: ReLU masks of both halves + BN-backward sums of the up half."""
     k = K()
@@ -156,8 +156,13 @@ def test_d0_dgrad_kernel(shape, stats):
     dA = F.conv2d(rounded(dz, BF), wt, stride=2, padding=1)              # [B,128,Hs,Ws]
     master = wt.permute(0, 2, 3, 1).contiguous().view(-1).to(DEV)       # [128][16]
     ref0 = rounded(torch.randn(B, 64, Hs, Ws), BF)
-    ref1 = rounded(torch.randn(B, 64, Hs, Ws), BF)
     z1 = rounded(torch.randn(B, 64, Hs, Ws), BF)
+    if stats == 'zmask':       # ref1 as the forward's apply kernel writes it: the kernel takes the mask from z, scale, shift
+        scale, shift = torch.randn(64) * 0.5 + 1.0, torch.randn(64) * 0.3
+        scale[::5] *= -1.0
+        ref1 = rounded(F.relu(torch.addcmul(shift.view(1, -1, 1, 1), z1, scale.view(1, -1, 1, 1))), BF)
+    else:
+        ref1 = rounded(torch.randn(B, 64, Hs, Ws), BF)
     mean, istd = torch.randn(64) * 0.1, torch.rand(64) + 0.5
     g0 = dA[:, :64] * (ref0 > 0)
     g1 = dA[:, 64:] * (ref1 > 0)
@@ -167,8 +172,9 @@ def test_d0_dgrad_kernel(shape, stats):
     part = torch.full((P, 2, 64), float('nan'), device=DEV)
     s0 = k.Seg(64, out0=o0, ref=nhwc(ref0, BF), slope=0.0)
     if stats:
+        extra = dict(scale=scale.to(DEV), shift=shift.to(DEV)) if stats == 'zmask' else {}
         s1 = k.Seg(64, out0=o1, ref=nhwc(ref1, BF), slope=0.0, z=nhwc(z1, BF), mean=mean.to(DEV), istd=istd.to(DEV),
-                   partials=part)
+                   partials=part, **extra)
     else:
         s1 = k.Seg(64, out0=o1, ref=nhwc(ref1, BF), slope=0.0)
     k.d0_dgrad(dz.to(DEV), master, B, Hs, Ws, s0, s1)
