@@ -122,7 +122,8 @@ def main():
             ref, z = torch.randn_like(out), torch.randn_like(out)
             mean, istd = torch.zeros(N, device=DEV), torch.ones(N, device=DEV)
             fn = lambda: K.igemm(T, geom, B, Hs, Hs, in0, in1, w, N, 3,
-                                 [K.Seg(N, out0=out, ref=ref, slope=0.2, z=z, mean=mean, istd=istd, partials=part)], ws)
+                                 [K.Seg(N, out0=out, ref=ref, slope=0.2, z=z, mean=mean, istd=istd, partials=part,
+                                        scale=istd, shift=mean)], ws)      # (scale / shift as the engine passes them: mask from z)
         else:
             fn = lambda: K.igemm(T, geom, B, Hs, Hs, in0, in1, w, N, 1, [K.Seg(N, out0=out, partials=part)], ws)
         t = timeit(fn, args.iters)

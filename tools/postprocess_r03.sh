@@ -1,4 +1,4 @@
-# Turns gpurun_out/r3/final (written on the GPU box by tools/final_measure_r03.sh + tools/secondary_r02.sh) into the
+# Turns gpurun_out/r3/final (written on the GPU box by tools/final_measure_r03.sh + tools/secondary_r03.sh) into the
 # committed summaries profiles/r03_*.  Run in the build container after the gpurun call.
 set -e
 cd "$(dirname "$0")/.."
@@ -33,6 +33,6 @@ PAT='^(igemm_ring_kernel|igemm_mfma_kernel<unsigned short, 128, 128, 2, 0, true>
 cp $F/bench_n1.json profiles/r03_bench_n1.json
 for f in gemm_microbench s1_gemm_microbench mx8_microbench; do grep -v amdgpu.ids $F/$f.txt > profiles/r03_$f.txt; done
 if [ -f $F/secondary_workloads.txt ]; then
-  { echo "# tools/secondary_r02.sh: tools/bench_model.py per workload (B = 32, one MI355X): GEMM families (ms per step, launches, TFLOP/s) + the hipGraph step"; cat $F/secondary_workloads.txt; } > profiles/r03_secondary_workloads.txt
+  { echo "# tools/secondary_r03.sh: tools/bench_model.py per workload (B = 32, one MI355X): GEMM families (ms per step, launches, TFLOP/s) + the hipGraph step"; cat $F/secondary_workloads.txt; } > profiles/r03_secondary_workloads.txt
 fi
 ls -la profiles/r03_*
