@@ -289,3 +289,25 @@ def test_binaural_entry_point_on_disk_dataset_with_worker_processes(tmp_path, mo
     assert ck['epoch'] == 2 and float(next(iter(ck['optimizer_state_dict']['state'].values()))['step']) == 6   # 6 items / 2
     assert all(torch.isfinite(v).all() for v in ck['model_state_dict'].values() if v.is_floating_point())
     assert set(ck['model_state_dict']) == set(model.state_dict())
+
+
+def test_debug_entry_points():
+    """adn_debug_stream_rmw (the overlap experiment's stand-in for the all-reduce's local traffic: dst += src as uint32, any
+    workgroup count, `passes` times) and adn_debug_poison_lds (must leave results of the next launch untouched)."""
+    import ctypes as C
+    from audio_depth_estimation_amd import _lib
+    lib = _lib.load()
+    n = 4 * 1000 + 4
+    src = torch.arange(n, dtype=torch.int32, device='cuda')
+    dst = torch.full((n,), 7, dtype=torch.int32, device='cuda')
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for wgs, passes in ((1, 1), (16, 3), (300, 2)):
+        before = dst.clone()
+        _lib.check(lib.adn_debug_stream_rmw(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), n * 4, wgs, passes, st),
+                   'adn_debug_stream_rmw')
+        assert torch.equal(dst, before + passes * src)
+    assert lib.adn_debug_stream_rmw(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), 10, 1, 1, st) != 0     # not 16-byte sized
+    _lib.check(lib.adn_debug_poison_lds(st), 'adn_debug_poison_lds')
+    a = torch.rand(3, 5, device='cuda')
+    assert torch.equal(a + 0, a)
+    torch.cuda.synchronize()
