@@ -247,7 +247,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_k4_patch_kernel(KParams4 p) {
   constexpr int PPIECES = (PPIX * 64 + 1023) / 1024;                             // 21 (16 pixels each)
   constexpr int PK = (PPIECES + 3) / 4;                                          // 6 per wave
   constexpr int PBUF = 4 * PK * 1024;                                            // (24 pieces: every wave issues PK requests)
-  constexpr unsigned OOB = 0x80000000u;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* DZl = smem;                    // [2][DZBUF]
   char* Pl = smem + 2 * DZBUF;         // [2][PBUF]
@@ -294,11 +293,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_k4_patch_kernel(KParams4 p) {
                           ((q >= PPIX || wave + 4 * k >= PPIECES) ? 16u : 0u);
     pmask |= bits << (5 * k);
   }
-  typedef __attribute__((address_space(3))) void* lptr_t;
-  const __amdgpu_buffer_rsrc_t rsd =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(psecond ? p.plain1 : p.plain0), 0, 0x7ffffff0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(reinterpret_cast<const char*>(gsecond ? p.gath1 : p.gath0) - (int64_t)bshift * Cs * 2), 0, 0x7ffffff0, 0x00020000);
 
   // the same descriptors as plain SGPR quadruples for the inline-assembly requests (see k4_dma)
   auto desc_of = [](const void* ptr) -> u32x4_t {
@@ -377,7 +371,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_k4_patch_kernel(KParams4 p) {
   const unsigned pbase = (unsigned)(2 * DZBUF + ((fg + kyh) * PW + qq) * 64 + ((wct ^ ((fg + kyh) & 1)) << 5) + pp * 8);
 
   using I0 = std::integral_constant<int, 0>;
-  using I4 = std::integral_constant<int, 4>;
   using I8 = std::integral_constant<int, 2 + PK>;
   // one pixel tile out of buffer CUR; the next tile's requests go into buffer CUR ^ 1
   auto tile_body = [&](auto CUR, bool more) {
