@@ -95,6 +95,8 @@ _PROTOS = {
     'adn_igemm': (C.c_int, [C.POINTER(AdnIgemmDesc), c_void_p]),
     'adn_wgrad_workspace_bytes': (c_int64, [C.POINTER(AdnWgradDesc)]),
     'adn_wgrad': (C.c_int, [C.POINTER(AdnWgradDesc), c_void_p]),
+    'adn_wgrad_batchable': (c_int32, [C.POINTER(AdnWgradDesc)]),
+    'adn_wgrad_batch': (C.c_int, [C.POINTER(AdnWgradDesc), c_int32, c_void_p]),
     'adn_wgrad_sq_count': (c_int32, [C.POINTER(AdnWgradDesc)]),
     'adn_pack_weights': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     'adn_mx8_quantize': (C.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),

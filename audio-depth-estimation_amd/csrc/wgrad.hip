@@ -548,12 +548,23 @@ bool adn_wgrad_s1p_plan(const AdnWgradDesc* d, int* nsplit, int64_t* out_elems);
 int adn_wgrad_s1p_launch(const AdnWgradDesc* d, int nsplit, int64_t out_elems, void* stream);
 
 int32_t adn_wgrad_k4_sq_count(const AdnWgradDesc* d);   // wgrad_k4.hip
+int32_t adn_wgrad_k4_batchable(const AdnWgradDesc* d);
+int adn_wgrad_k4_batch(const AdnWgradDesc* descs, int32_t n, void* stream);
 
 // Norm partials ride along only in the k4 pair's kernels (the U-Net baseline: 54 M parameters, the gradient pass the
 // fusion saves is 40 us of a 2.9 ms step); the stride-1 kernels of the DoubleConv nets report 0 = "not fused".
 extern "C" int32_t adn_wgrad_sq_count(const AdnWgradDesc* d) {
   if (!d || d->geom == ADN_GEMM_S1) return 0;
   return adn_wgrad_k4_sq_count(d);
+}
+
+extern "C" int32_t adn_wgrad_batchable(const AdnWgradDesc* d) {
+  if (!d || d->geom == ADN_GEMM_S1) return 0;
+  return adn_wgrad_k4_batchable(d);
+}
+
+extern "C" int adn_wgrad_batch(const AdnWgradDesc* descs, int32_t n, void* stream) {
+  return adn_wgrad_k4_batch(descs, n, stream);
 }
 
 extern "C" int64_t adn_wgrad_workspace_bytes(const AdnWgradDesc* d) {

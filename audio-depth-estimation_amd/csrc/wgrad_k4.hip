@@ -42,8 +42,10 @@ __device__ u32x4_t adn_wg4_zero_page[8];
 
 __device__ __forceinline__ int swz_f(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
+// (the body is shared by the one-problem kernel and the multi-problem launch of the small-image layers: `bid` is the
+//  workgroup index inside its problem)
 template <typename T, bool FAST>
-__global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
+__device__ __forceinline__ void wgrad_mfma_body(const WParams& p, const int bid) {
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins exist only in the device pass
   constexpr int EPC = 16 / (int)sizeof(T);
   constexpr int BKP = sizeof(T) == 2 ? 64 : 32;       // pixels per step
@@ -63,8 +65,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
   // operands through its L2 (blocks b and b+8 share an XCD)
   const int ntile = p.tiles_r * p.tiles_c;
   const int nblk = ntile * p.nsplit;
-  const int bq = nblk >> 3, br = nblk & 7, bx = blockIdx.x & 7;
-  const int lid = (bx < br ? bx * (bq + 1) : br * (bq + 1) + (bx - br) * bq) + (blockIdx.x >> 3);
+  const int bq = nblk >> 3, br = nblk & 7, bx = bid & 7;
+  const int lid = (bx < br ? bx * (bq + 1) : br * (bq + 1) + (bx - br) * bq) + (bid >> 3);
   const int tile_c = lid % p.tiles_c;
   const int tile_r = (lid / p.tiles_c) % p.tiles_r;
   const int split = lid / ntile;
@@ -331,6 +333,28 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
 #endif
 }
 
+template <typename T, bool FAST>
+__global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WParams p) {
+  wgrad_mfma_body<T, FAST>(p, (int)blockIdx.x);
+}
+
+// Several independent weight-gradient problems in ONE launch (the small-image levels of the U-Net: six launches of
+// 256-512 short workgroups each, whose time is launch ramp and dW write latency, not arithmetic).
+constexpr int kWgradBatchMax = 8;
+struct WBatch {
+  WParams p[kWgradBatchMax];
+  int first[kWgradBatchMax + 1];      // first workgroup of problem k; first[n] = grid size
+  int n;
+};
+template <typename T, bool FAST>
+__global__ __launch_bounds__(256, 2) void wgrad_mfma_batch_kernel(WBatch b) {
+  int k = 0;
+#pragma unroll
+  for (int j = 1; j < kWgradBatchMax; ++j)
+    if (j < b.n && (int)blockIdx.x >= b.first[j]) k = j;
+  wgrad_mfma_body<T, FAST>(b.p[k], (int)blockIdx.x - b.first[k]);
+}
+
 // generic path: one thread per (output element, split)
 template <typename T>
 __global__ __launch_bounds__(256) void wgrad_direct_kernel(WParams p, int pix_per_split) {
@@ -465,9 +489,7 @@ int wvalidate(const AdnWgradDesc* d) {
   return ADN_OK;
 }
 
-template <typename T>
-int wrun(const AdnWgradDesc* d, const WPlan& pl, hipStream_t st) {
-  WParams p;
+void fill_wparams(const AdnWgradDesc* d, const WPlan& pl, WParams& p) {
   p.plain0 = d->plain0; p.plain1 = d->plain1; p.R0 = d->R0; p.R1 = d->R1;
   p.gath0 = d->gath0; p.gath1 = d->gath1; p.C0 = d->C0; p.C1 = d->C1;
   p.B = d->B; p.Hs = d->Hs; p.Ws = d->Ws; p.Msmall = d->B * d->Hs * d->Ws;
@@ -476,6 +498,12 @@ int wrun(const AdnWgradDesc* d, const WPlan& pl, hipStream_t st) {
   p.out_elems = pl.out_elems;
   p.c_valid = d->c_valid > 0 ? d->c_valid : d->C0 + d->C1;
   p.sq = (pl.mfma && pl.nsplit == 1 && p.c_valid == d->C0 + d->C1) ? d->sq_partials : nullptr;
+}
+
+template <typename T>
+int wrun(const AdnWgradDesc* d, const WPlan& pl, hipStream_t st) {
+  WParams p;
+  fill_wparams(d, pl, p);
   if (pl.mfma) {
     constexpr int BKP = sizeof(T) == 2 ? 64 : 32;
     constexpr int stage = 4 * BKP * 128 * (int)sizeof(T);
@@ -532,6 +560,42 @@ int32_t adn_wgrad_k4_sq_count(const AdnWgradDesc* d) {
   const int cv = d->c_valid > 0 ? d->c_valid : d->C0 + d->C1;
   if (pl.mfma && cv == d->C0 + d->C1) return pl.tiles_r * pl.tiles_c;
   return 0;
+}
+
+// 1 when `d` can be one problem of adn_wgrad_k4_batch: bf16, the tap-staged MFMA kernel in its general (not power-of-two
+// fast) form, unsplit (it writes the final dW itself)
+int32_t adn_wgrad_k4_batchable(const AdnWgradDesc* d) {
+  if (wvalidate(d) != ADN_OK || d->dtype != ADN_BF16) return 0;
+  int ns;
+  int64_t oe;
+  if (adn_wgrad_k4p_plan(d, &ns, &oe)) return 0;
+  WPlan pl;
+  make_wplan(d, &pl);
+  return pl.mfma && !pl.fast && pl.nsplit == 1 ? 1 : 0;
+}
+
+int adn_wgrad_k4_batch(const AdnWgradDesc* descs, int32_t n, void* stream) {
+  ADN_CHECK_ARG(descs && n >= 1 && n <= kWgradBatchMax, "adn_wgrad_batch: 1 .. %d problems (got %d)", kWgradBatchMax, n);
+  WBatch b;
+  b.n = n;
+  b.first[0] = 0;
+  for (int k = 0; k < n; ++k) {
+    ADN_CHECK_ARG(adn_wgrad_k4_batchable(descs + k), "adn_wgrad_batch: problem %d is not batchable (adn_wgrad_batchable)", k);
+    WPlan pl;
+    make_wplan(descs + k, &pl);
+    fill_wparams(descs + k, pl, b.p[k]);
+    b.first[k + 1] = b.first[k] + pl.tiles_r * pl.tiles_c;
+  }
+  for (int k = n; k < kWgradBatchMax; ++k) {
+    b.p[k] = b.p[0];
+    b.first[k + 1] = b.first[n];
+  }
+  constexpr int lds = 128 * 132 * 4 > 4 * 64 * 128 * 2 ? 128 * 132 * 4 : 4 * 64 * 128 * 2;
+  ADN_SET_LDS_ONCE(lds, &wgrad_mfma_batch_kernel<uint16_t, false>);
+  hipLaunchKernelGGL((wgrad_mfma_batch_kernel<uint16_t, false>), dim3((unsigned)b.first[n]), dim3(256), lds,
+                     reinterpret_cast<hipStream_t>(stream), b);
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
 }
 
 int adn_wgrad_k4(const AdnWgradDesc* d, void* stream) {

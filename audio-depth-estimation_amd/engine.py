@@ -165,6 +165,9 @@ class UNetEngine(FlatParamEngine):
                 w6 = K.thin_wgrad_workspace_bytes(B, hs, wsz, 1, 64, 64)
             ws_bytes = max(ws_bytes, w1, w2, w3, w4, w5, w6)
             lv.update(P_d=pd, P_u=pu, P_gu=pgu, P_gd=pgd)
+            # small-image levels: their weight gradients ride in one multi-problem launch (adn_wgrad_batch)
+            lv['wb_d'] = (not edge0 and cd_in_p == cd_in and K.wgrad_batchable(T, B, hs, wsz, cd_out, 0, cd_in_p, 0))
+            lv['wb_u'] = (not edge0 and cu_out_p == cu_out and K.wgrad_batchable(T, B, hs, wsz, c_up0, c_up1, cu_out_p, 0))
             for tag, bn, C in (('d', lv['bn_d'], cd_out), ('u', lv['bn_u'], cu_out)):
                 if bn is None:
                     continue
@@ -373,6 +376,14 @@ class UNetEngine(FlatParamEngine):
             if up0.bias is not None:
                 K.sum_to_scalar(l0['dz0'], self._flat_slice(self.flat_g, up0.bias), self.red_ws)
         # ---- up layers, outermost first
+        # (weight gradients of the small-image levels are collected and launched together: nothing inside backward reads
+        #  them, and their operands stay untouched until the end of the pass)
+        batch = [] if (self.on_grad_ready is None and T == torch.bfloat16 and not os.environ.get('ADN_NO_WGRAD_BATCH')) else None
+
+        def flush():
+            if batch:
+                K.wgrad_batch(T, B, batch)
+                del batch[:]
         for i in range(n):
             lv = L[i]
             hs, wsz = lv['hs'], lv['ws']
@@ -394,9 +405,13 @@ class UNetEngine(FlatParamEngine):
                 self._ready(lv['up'].weight)
                 K.d0_dgrad(dz, self._flat_slice(self.flat_p, lv['up'].weight), B, hs, wsz, segs[0], segs[1])
                 continue
-            K.wgrad(T, B, hs, wsz, in0, in1, dz, None, self._flat_slice(self.flat_g, lv['up'].weight), ws,
-                    c_valid=lv['cu_out'] if (i == 0 and self.cout_pad != lv['cu_out']) else 0,
-                    sq=lv['up_sq'] if fused_norm else None)
+            if batch is not None and lv['wb_u']:
+                batch.append((hs, wsz, in0, in1, dz, None, self._flat_slice(self.flat_g, lv['up'].weight),
+                              lv['up_sq'] if fused_norm else None))
+            else:
+                K.wgrad(T, B, hs, wsz, in0, in1, dz, None, self._flat_slice(self.flat_g, lv['up'].weight), ws,
+                        c_valid=lv['cu_out'] if (i == 0 and self.cout_pad != lv['cu_out']) else 0,
+                        sq=lv['up_sq'] if fused_norm else None)
             self._ready(lv['up'].weight)
             K.igemm(T, GEMM_S2, B, hs, wsz, dz, None, lv['up_s2'], lv['cu_in'], EPI_BWD, segs, ws,
                     algo_c=lv['cu_out'])
@@ -411,7 +426,13 @@ class UNetEngine(FlatParamEngine):
                 if self._x_in._version != self._x_ver:
                     raise RuntimeError('the network input was modified in place between forward and backward')
                 K.thin_wgrad(self._x_in, lv['Gd'], None, B, hs, wsz, self._flat_slice(self.flat_g, lv['down'].weight), ws)
+            elif batch is not None and lv['wb_d']:
+                if len(batch) == 8:
+                    flush()
+                batch.append((hs, wsz, lv['Gd'], None, src, None, self._flat_slice(self.flat_g, lv['down'].weight),
+                              lv['down_sq'] if fused_norm else None))
             else:
+                flush()                                   # back at the wide levels: the collected small ones go first
                 K.wgrad(T, B, hs, wsz, lv['Gd'], None, src, None, self._flat_slice(self.flat_g, lv['down'].weight), ws,
                         c_valid=lv['cd_in'] if (i == 0 and self.cin_pad != lv['cd_in']) else 0,
                         sq=lv['down_sq'] if fused_norm else None)
@@ -424,6 +445,7 @@ class UNetEngine(FlatParamEngine):
                                 z=pv['zd'], mean=pv['mean_d'], istd=pv['istd_d'], partials=pv['bpart_d'],
                                 scale=pv['scale_d'], shift=pv['shift_d'])
                 K.igemm(T, GEMM_T2, B, hs, wsz, lv['Gd'], None, lv['down_t2'], lv['cd_in'], EPI_BWD, [seg], ws)
+        flush()
         if self.on_grad_ready is not None:
             _lib.record_py(lambda: self.on_grad_ready(0))
 

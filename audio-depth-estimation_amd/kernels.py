@@ -164,6 +164,34 @@ def wgrad_workspace_bytes(dtype, B, Hs, Ws, R0, R1, C0, C1, c_valid=0, ks=0):
     return n
 
 
+def wgrad_batchable(dtype, B, Hs, Ws, R0, R1, C0, C1, c_valid=0):
+    """True when this k4 weight gradient can ride in a wgrad_batch launch (host-only query)."""
+    d = AdnWgradDesc()
+    d.c_valid = c_valid
+    d.geom, d.ks = 0, 0
+    d.dtype, d.B, d.Hs, d.Ws, d.R0, d.R1, d.C0, d.C1 = dtype_code(dtype), B, Hs, Ws, R0, R1, C0, C1
+    d.plain0 = d.gath0 = d.dw = 1
+    d.plain1 = 1 if R1 else None
+    d.gath1 = 1 if C1 else None
+    return bool(_lib.load().adn_wgrad_batchable(C.byref(d)))
+
+
+def wgrad_batch(dtype, B, problems):
+    """problems: list of (Hs, Ws, plain0, plain1, gath0, gath1, dw, sq): up to 8 weight gradients in one launch."""
+    arr = (AdnWgradDesc * len(problems))()
+    flops = 0.0
+    for slot, (Hs, Ws, p0, p1, g0, g1, dw, sq) in zip(arr, problems):
+        d = _wgrad_desc(dtype, B, Hs, Ws, p0, p1, g0, g1, dw, None)
+        d.sq_partials = ptr(sq)
+        C.memmove(C.byref(slot), C.byref(d), C.sizeof(AdnWgradDesc))
+        flops += 2.0 * B * Hs * Ws * (d.R0 + d.R1) * 16 * (d.C0 + d.C1)
+    ev = _prof_begin()
+    _lib.call('adn_wgrad_batch', arr, len(problems), _stream())
+    _lib.annotate(label='wgrad', flops=flops)
+    if ev is not None:
+        _prof_end(ev, 'wgrad', flops)
+
+
 def wgrad_sq_count(dtype, B, Hs, Ws, R0, R1, C0, C1, c_valid=0, ks=0):
     """Partial sums of dW^2 adn_wgrad leaves behind when asked to (``sq=``); 0 = this layer's kernel has no fused form."""
     d = AdnWgradDesc()

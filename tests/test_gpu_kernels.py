@@ -340,6 +340,41 @@ def test_epilogue_bwd_two_segments(dtype, shape):
     assert rel_err(from_nhwc(g0), acc_ref) <= 2 * TOL_T_OUT[dtype]
 
 
+def test_wgrad_batch_equals_single_launches():
+    """adn_wgrad_batch (several small-image weight gradients in one launch) is bit-identical to one adn_wgrad per problem,
+    dW and the norm partials alike; a problem the unsplit tap-staged kernel does not take is refused."""
+    k = K()
+    dtype, B = torch.bfloat16, 32
+    torch.manual_seed(19)
+    shapes = [(2, 512, 0, 512), (1, 512, 0, 512), (2, 512, 512, 512), (4, 512, 512, 512), (1, 128, 0, 256)]   # Hs, R0, R1, C
+    probs, singles = [], []
+    for Hs, R0, R1, C in shapes:
+        assert k.wgrad_batchable(dtype, B, Hs, Hs, R0, R1, C, 0), (Hs, R0, R1, C)
+        p0 = torch.randn(B, Hs, Hs, R0, device=DEV).to(dtype)
+        p1 = torch.randn(B, Hs, Hs, R1, device=DEV).to(dtype) if R1 else None
+        g = torch.randn(B, 2 * Hs, 2 * Hs, C, device=DEV).to(dtype)
+        n = (R0 + R1) * 16 * C
+        nsq = k.wgrad_sq_count(dtype, B, Hs, Hs, R0, R1, C, 0)
+        assert nsq > 0
+        ws = torch.empty(max(k.wgrad_workspace_bytes(dtype, B, Hs, Hs, R0, R1, C, 0), 16) // 4, device=DEV)
+        dw_ref, sq_ref = torch.empty(n, device=DEV), torch.zeros(nsq, dtype=torch.float64, device=DEV)
+        k.wgrad(dtype, B, Hs, Hs, p0, p1, g, None, dw_ref, ws, sq=sq_ref)
+        dw, sq = torch.full((n,), float('nan'), device=DEV), torch.full((nsq,), float('nan'), dtype=torch.float64, device=DEV)
+        probs.append((Hs, Hs, p0, p1, g, None, dw, sq))
+        singles.append((dw_ref, sq_ref))
+    k.wgrad_batch(dtype, B, probs)
+    for (_, _, _, _, _, _, dw, sq), (dw_ref, sq_ref) in zip(probs, singles):
+        assert torch.equal(dw, dw_ref) and torch.equal(sq, sq_ref)
+    k.wgrad_batch(dtype, B, [probs[1][:7] + (None,)])                      # one problem, no norm partials
+    assert torch.equal(probs[1][6], singles[1][0])
+    assert not k.wgrad_batchable(dtype, B, 64, 64, 128, 0, 64, 0)         # a patch-staged layer
+    Hs = 64
+    bad = (Hs, Hs, torch.zeros(B, Hs, Hs, 128, device=DEV, dtype=dtype), None,
+           torch.zeros(B, 2 * Hs, 2 * Hs, 64, device=DEV, dtype=dtype), None, torch.empty(128 * 16 * 64, device=DEV), None)
+    with pytest.raises(RuntimeError, match='not batchable'):
+        k.wgrad_batch(dtype, B, [bad])
+
+
 @pytest.mark.parametrize('accumulate', [False, True])
 @pytest.mark.parametrize('geom,shape', [(0, (16, 128, 128, 64)), (0, (32, 64, 256, 64)), (1, (16, 256, 128, 16)),
                                         (1, (8, 128, 64, 32)), (0, (2, 128, 128, 8))])
