@@ -96,6 +96,7 @@ _PROTOS = {
     'adn_wgrad_workspace_bytes': (c_int64, [C.POINTER(AdnWgradDesc)]),
     'adn_wgrad': (C.c_int, [C.POINTER(AdnWgradDesc), c_void_p]),
     'adn_wgrad_batchable': (c_int32, [C.POINTER(AdnWgradDesc)]),
+    'adn_wgrad_batch_sq_count': (c_int32, [C.POINTER(AdnWgradDesc)]),
     'adn_wgrad_batch': (C.c_int, [C.POINTER(AdnWgradDesc), c_int32, c_void_p]),
     'adn_wgrad_sq_count': (c_int32, [C.POINTER(AdnWgradDesc)]),
     'adn_pack_weights': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),

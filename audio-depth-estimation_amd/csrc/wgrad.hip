@@ -549,6 +549,7 @@ int adn_wgrad_s1p_launch(const AdnWgradDesc* d, int nsplit, int64_t out_elems, v
 
 int32_t adn_wgrad_k4_sq_count(const AdnWgradDesc* d);   // wgrad_k4.hip
 int32_t adn_wgrad_k4_batchable(const AdnWgradDesc* d);
+int32_t adn_wgrad_k4_batch_sq_count(const AdnWgradDesc* d);
 int adn_wgrad_k4_batch(const AdnWgradDesc* descs, int32_t n, void* stream);
 
 // Norm partials ride along only in the k4 pair's kernels (the U-Net baseline: 54 M parameters, the gradient pass the
@@ -561,6 +562,11 @@ extern "C" int32_t adn_wgrad_sq_count(const AdnWgradDesc* d) {
 extern "C" int32_t adn_wgrad_batchable(const AdnWgradDesc* d) {
   if (!d || d->geom == ADN_GEMM_S1) return 0;
   return adn_wgrad_k4_batchable(d);
+}
+
+extern "C" int32_t adn_wgrad_batch_sq_count(const AdnWgradDesc* d) {
+  if (!d || d->geom == ADN_GEMM_S1) return 0;
+  return adn_wgrad_k4_batch_sq_count(d);
 }
 
 extern "C" int adn_wgrad_batch(const AdnWgradDesc* descs, int32_t n, void* stream) {

@@ -562,16 +562,27 @@ int32_t adn_wgrad_k4_sq_count(const AdnWgradDesc* d) {
   return 0;
 }
 
-// 1 when `d` can be one problem of adn_wgrad_k4_batch: bf16, the tap-staged MFMA kernel in its general (not power-of-two
-// fast) form, unsplit (it writes the final dW itself)
+// 0: `d` cannot ride in adn_wgrad_k4_batch; 1 / 2: it can, in the general / power-of-two-image ("fast") form of the
+// tap-staged MFMA kernel (a launch holds problems of ONE class).  Inside a batch every problem runs UNSPLIT -- the other
+// problems of the launch provide the parallelism a lone launch gets from splitting the pixels -- so it writes the final dW
+// (no slab sum) and tiles_r * tiles_c norm partials (adn_wgrad_k4_batch_sq_count).
 int32_t adn_wgrad_k4_batchable(const AdnWgradDesc* d) {
   if (wvalidate(d) != ADN_OK || d->dtype != ADN_BF16) return 0;
+  if (d->c_valid > 0 && d->c_valid != d->C0 + d->C1) return 0;
   int ns;
   int64_t oe;
   if (adn_wgrad_k4p_plan(d, &ns, &oe)) return 0;
   WPlan pl;
   make_wplan(d, &pl);
-  return pl.mfma && !pl.fast && pl.nsplit == 1 ? 1 : 0;
+  if (!pl.mfma || pl.nsplit > 2) return 0;             // (a layer that wants many pixel splits is not a small one)
+  return pl.fast ? 2 : 1;
+}
+
+int32_t adn_wgrad_k4_batch_sq_count(const AdnWgradDesc* d) {
+  if (!adn_wgrad_k4_batchable(d)) return 0;
+  WPlan pl;
+  make_wplan(d, &pl);
+  return pl.tiles_r * pl.tiles_c;
 }
 
 int adn_wgrad_k4_batch(const AdnWgradDesc* descs, int32_t n, void* stream) {
@@ -579,10 +590,14 @@ int adn_wgrad_k4_batch(const AdnWgradDesc* descs, int32_t n, void* stream) {
   WBatch b;
   b.n = n;
   b.first[0] = 0;
+  const int32_t cls = adn_wgrad_k4_batchable(descs);
   for (int k = 0; k < n; ++k) {
-    ADN_CHECK_ARG(adn_wgrad_k4_batchable(descs + k), "adn_wgrad_batch: problem %d is not batchable (adn_wgrad_batchable)", k);
+    const int32_t c = adn_wgrad_k4_batchable(descs + k);
+    ADN_CHECK_ARG(c != 0, "adn_wgrad_batch: problem %d is not batchable (adn_wgrad_batchable)", k);
+    ADN_CHECK_ARG(c == cls, "adn_wgrad_batch: problem %d is of class %d, problem 0 of class %d (one class per launch)", k, c, cls);
     WPlan pl;
     make_wplan(descs + k, &pl);
+    pl.nsplit = 1;
     fill_wparams(descs + k, pl, b.p[k]);
     b.first[k + 1] = b.first[k] + pl.tiles_r * pl.tiles_c;
   }
@@ -591,9 +606,14 @@ int adn_wgrad_k4_batch(const AdnWgradDesc* descs, int32_t n, void* stream) {
     b.first[k + 1] = b.first[n];
   }
   constexpr int lds = 128 * 132 * 4 > 4 * 64 * 128 * 2 ? 128 * 132 * 4 : 4 * 64 * 128 * 2;
-  ADN_SET_LDS_ONCE(lds, &wgrad_mfma_batch_kernel<uint16_t, false>);
-  hipLaunchKernelGGL((wgrad_mfma_batch_kernel<uint16_t, false>), dim3((unsigned)b.first[n]), dim3(256), lds,
-                     reinterpret_cast<hipStream_t>(stream), b);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (cls == 2) {
+    ADN_SET_LDS_ONCE(lds, &wgrad_mfma_batch_kernel<uint16_t, true>);
+    hipLaunchKernelGGL((wgrad_mfma_batch_kernel<uint16_t, true>), dim3((unsigned)b.first[n]), dim3(256), lds, st, b);
+  } else {
+    ADN_SET_LDS_ONCE(lds, &wgrad_mfma_batch_kernel<uint16_t, false>);
+    hipLaunchKernelGGL((wgrad_mfma_batch_kernel<uint16_t, false>), dim3((unsigned)b.first[n]), dim3(256), lds, st, b);
+  }
   ADN_CHECK_LAUNCH();
   return ADN_OK;
 }

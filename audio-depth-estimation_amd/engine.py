@@ -166,8 +166,12 @@ class UNetEngine(FlatParamEngine):
             ws_bytes = max(ws_bytes, w1, w2, w3, w4, w5, w6)
             lv.update(P_d=pd, P_u=pu, P_gu=pgu, P_gd=pgd)
             # small-image levels: their weight gradients ride in one multi-problem launch (adn_wgrad_batch)
-            lv['wb_d'] = (not edge0 and cd_in_p == cd_in and K.wgrad_batchable(T, B, hs, wsz, cd_out, 0, cd_in_p, 0))
-            lv['wb_u'] = (not edge0 and cu_out_p == cu_out and K.wgrad_batchable(T, B, hs, wsz, c_up0, c_up1, cu_out_p, 0))
+            # (class of the problem -- a launch holds one class -- and its number of norm partials; 0 = own launch)
+            batching = T == torch.bfloat16 and not os.environ.get('ADN_NO_WGRAD_BATCH')
+            lv['wb_d'], lv['wbq_d'] = (K.wgrad_batchable(T, B, hs, wsz, cd_out, 0, cd_in_p, 0)
+                                       if batching and not edge0 and cd_in_p == cd_in else (0, 0))
+            lv['wb_u'], lv['wbq_u'] = (K.wgrad_batchable(T, B, hs, wsz, c_up0, c_up1, cu_out_p, 0)
+                                       if batching and not edge0 and cu_out_p == cu_out else (0, 0))
             for tag, bn, C in (('d', lv['bn_d'], cd_out), ('u', lv['bn_u'], cu_out)):
                 if bn is None:
                     continue
@@ -229,6 +233,10 @@ class UNetEngine(FlatParamEngine):
                                                   lv['cd_in'] if lv['down_ypad'] != lv['cd_in'] else 0)
             nu = 0 if edge0 else K.wgrad_sq_count(T, B, hs, wsz, c_up0, c_up1, lv['up_ypad'], 0,
                                                   lv['cu_out'] if lv['up_ypad'] != lv['cu_out'] else 0)
+            if lv['wb_d']:                   # a problem of the multi-problem launch runs unsplit: its own partial count
+                nd = lv['wbq_d']
+            if lv['wb_u']:
+                nu = lv['wbq_u']
             for wk, cnt in (('down', nd), ('up', nu)):
                 counts.append((lv, wk, cnt))
                 if cnt:
@@ -378,12 +386,16 @@ class UNetEngine(FlatParamEngine):
         # ---- up layers, outermost first
         # (weight gradients of the small-image levels are collected and launched together: nothing inside backward reads
         #  them, and their operands stay untouched until the end of the pass)
-        batch = [] if (self.on_grad_ready is None and T == torch.bfloat16 and not os.environ.get('ADN_NO_WGRAD_BATCH')) else None
+        batch = {1: [], 2: []}            # per problem class (kernels.wgrad_batchable)
+        # (the reducer's gradient-ready hook wants every dW as early as possible: the same problems then go out as
+        #  one-problem launches of the same kernel form -- unsplit --, so both modes produce identical bits)
+        use_batch = self.on_grad_ready is None
 
-        def flush():
-            if batch:
-                K.wgrad_batch(T, B, batch)
-                del batch[:]
+        def flush(cls=None):
+            for c in ((cls,) if cls else (1, 2)):
+                if batch[c]:
+                    K.wgrad_batch(T, B, batch[c])
+                    del batch[c][:]
         for i in range(n):
             lv = L[i]
             hs, wsz = lv['hs'], lv['ws']
@@ -405,9 +417,13 @@ class UNetEngine(FlatParamEngine):
                 self._ready(lv['up'].weight)
                 K.d0_dgrad(dz, self._flat_slice(self.flat_p, lv['up'].weight), B, hs, wsz, segs[0], segs[1])
                 continue
-            if batch is not None and lv['wb_u']:
-                batch.append((hs, wsz, in0, in1, dz, None, self._flat_slice(self.flat_g, lv['up'].weight),
-                              lv['up_sq'] if fused_norm else None))
+            if lv['wb_u']:
+                if len(batch[lv['wb_u']]) == 8:
+                    flush(lv['wb_u'])
+                batch[lv['wb_u']].append((hs, wsz, in0, in1, dz, None, self._flat_slice(self.flat_g, lv['up'].weight),
+                                          lv['up_sq'] if fused_norm else None))
+                if not use_batch:
+                    flush(lv['wb_u'])
             else:
                 K.wgrad(T, B, hs, wsz, in0, in1, dz, None, self._flat_slice(self.flat_g, lv['up'].weight), ws,
                         c_valid=lv['cu_out'] if (i == 0 and self.cout_pad != lv['cu_out']) else 0,
@@ -426,11 +442,14 @@ class UNetEngine(FlatParamEngine):
                 if self._x_in._version != self._x_ver:
                     raise RuntimeError('the network input was modified in place between forward and backward')
                 K.thin_wgrad(self._x_in, lv['Gd'], None, B, hs, wsz, self._flat_slice(self.flat_g, lv['down'].weight), ws)
-            elif batch is not None and lv['wb_d']:
-                if len(batch) == 8:
-                    flush()
-                batch.append((hs, wsz, lv['Gd'], None, src, None, self._flat_slice(self.flat_g, lv['down'].weight),
-                              lv['down_sq'] if fused_norm else None))
+            elif lv['wb_d']:
+                if len(batch[lv['wb_d']]) == 8:
+                    flush(lv['wb_d'])
+                batch[lv['wb_d']].append((hs, wsz, lv['Gd'], None, src, None,
+                                          self._flat_slice(self.flat_g, lv['down'].weight),
+                                          lv['down_sq'] if fused_norm else None))
+                if not use_batch:
+                    flush(lv['wb_d'])
             else:
                 flush()                                   # back at the wide levels: the collected small ones go first
                 K.wgrad(T, B, hs, wsz, lv['Gd'], None, src, None, self._flat_slice(self.flat_g, lv['down'].weight), ws,

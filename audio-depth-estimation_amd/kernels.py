@@ -165,7 +165,8 @@ def wgrad_workspace_bytes(dtype, B, Hs, Ws, R0, R1, C0, C1, c_valid=0, ks=0):
 
 
 def wgrad_batchable(dtype, B, Hs, Ws, R0, R1, C0, C1, c_valid=0):
-    """True when this k4 weight gradient can ride in a wgrad_batch launch (host-only query)."""
+    """(class, norm partials) of this k4 weight gradient as a problem of a wgrad_batch launch; class 0 = not batchable,
+    problems of one launch share their class (host-only query)."""
     d = AdnWgradDesc()
     d.c_valid = c_valid
     d.geom, d.ks = 0, 0
@@ -173,7 +174,8 @@ def wgrad_batchable(dtype, B, Hs, Ws, R0, R1, C0, C1, c_valid=0):
     d.plain0 = d.gath0 = d.dw = 1
     d.plain1 = 1 if R1 else None
     d.gath1 = 1 if C1 else None
-    return bool(_lib.load().adn_wgrad_batchable(C.byref(d)))
+    lib = _lib.load()
+    return int(lib.adn_wgrad_batchable(C.byref(d))), int(lib.adn_wgrad_batch_sq_count(C.byref(d)))
 
 
 def wgrad_batch(dtype, B, problems):

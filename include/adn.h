@@ -147,9 +147,12 @@ int64_t adn_wgrad_workspace_bytes(const AdnWgradDesc* d);
 int adn_wgrad(const AdnWgradDesc* d, void* stream);
 /* Up to 8 independent weight-gradient problems in ONE launch (k4 pair, bf16): the five 512-channel blocks of unet_256
  * (unetbaseline_model.py:141-148) have <= 4 x 4 images -- their weight gradients are six launches of 256-512 short
- * workgroups whose time is launch ramp and dW write latency.  Every problem must satisfy adn_wgrad_batchable (the
- * unsplit tap-staged kernel; it writes the final dW and, if asked, its sq_partials); results are those of adn_wgrad. */
+ * workgroups whose time is launch ramp and dW write latency.  adn_wgrad_batchable: 0 = not batchable, 1 / 2 = class of the
+ * problem (one class per launch).  Inside a batch every problem runs unsplit: it writes the final dW and, if asked,
+ * adn_wgrad_batch_sq_count(d) norm partials (not adn_wgrad_sq_count: a lone launch of the same layer may split the pixels
+ * and leave its partials to the slab sum); dW equals adn_wgrad's up to the summation order of a split launch. */
 int32_t adn_wgrad_batchable(const AdnWgradDesc* d);
+int32_t adn_wgrad_batch_sq_count(const AdnWgradDesc* d);
 int adn_wgrad_batch(const AdnWgradDesc* descs, int32_t n, void* stream);
 /* Number of doubles adn_wgrad writes to d->sq_partials (0: not fused for this descriptor). */
 int32_t adn_wgrad_sq_count(const AdnWgradDesc* d);

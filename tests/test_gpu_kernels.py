@@ -349,13 +349,13 @@ def test_wgrad_batch_equals_single_launches():
     shapes = [(2, 512, 0, 512), (1, 512, 0, 512), (2, 512, 512, 512), (4, 512, 512, 512), (1, 128, 0, 256)]   # Hs, R0, R1, C
     probs, singles = [], []
     for Hs, R0, R1, C in shapes:
-        assert k.wgrad_batchable(dtype, B, Hs, Hs, R0, R1, C, 0), (Hs, R0, R1, C)
+        assert k.wgrad_batchable(dtype, B, Hs, Hs, R0, R1, C, 0)[0] == 1, (Hs, R0, R1, C)
         p0 = torch.randn(B, Hs, Hs, R0, device=DEV).to(dtype)
         p1 = torch.randn(B, Hs, Hs, R1, device=DEV).to(dtype) if R1 else None
         g = torch.randn(B, 2 * Hs, 2 * Hs, C, device=DEV).to(dtype)
         n = (R0 + R1) * 16 * C
         nsq = k.wgrad_sq_count(dtype, B, Hs, Hs, R0, R1, C, 0)
-        assert nsq > 0
+        assert nsq > 0 and nsq == k.wgrad_batchable(dtype, B, Hs, Hs, R0, R1, C, 0)[1]      # (unsplit layers: the same count)
         ws = torch.empty(max(k.wgrad_workspace_bytes(dtype, B, Hs, Hs, R0, R1, C, 0), 16) // 4, device=DEV)
         dw_ref, sq_ref = torch.empty(n, device=DEV), torch.zeros(nsq, dtype=torch.float64, device=DEV)
         k.wgrad(dtype, B, Hs, Hs, p0, p1, g, None, dw_ref, ws, sq=sq_ref)
@@ -367,7 +367,27 @@ def test_wgrad_batch_equals_single_launches():
         assert torch.equal(dw, dw_ref) and torch.equal(sq, sq_ref)
     k.wgrad_batch(dtype, B, [probs[1][:7] + (None,)])                      # one problem, no norm partials
     assert torch.equal(probs[1][6], singles[1][0])
-    assert not k.wgrad_batchable(dtype, B, 64, 64, 128, 0, 64, 0)         # a patch-staged layer
+    assert k.wgrad_batchable(dtype, B, 64, 64, 128, 0, 64, 0) == (0, 0)   # a patch-staged layer
+    # a layer whose lone launch splits the pixels (slab sum) runs unsplit inside a batch: same dW up to the summation order,
+    # tiles_r * tiles_c norm partials; the power-of-two-image form is its own class
+    for (Hs, R0, R1, C), want in (((4, 512, 0, 512), 1), ((8, 512, 0, 512), 2), ((8, 512, 512, 512), 2)):
+        cls, nsq = k.wgrad_batchable(dtype, B, Hs, Hs, R0, R1, C, 0)
+        assert cls == want and nsq == ((R0 + R1) // 128) * (16 * C // 128)
+        p0 = torch.randn(B, Hs, Hs, R0, device=DEV).to(dtype)
+        p1 = torch.randn(B, Hs, Hs, R1, device=DEV).to(dtype) if R1 else None
+        g = torch.randn(B, 2 * Hs, 2 * Hs, C, device=DEV).to(dtype)
+        n = (R0 + R1) * 16 * C
+        ws = torch.empty(max(k.wgrad_workspace_bytes(dtype, B, Hs, Hs, R0, R1, C, 0), 16) // 4, device=DEV)
+        dw_ref = torch.empty(n, device=DEV)
+        k.wgrad(dtype, B, Hs, Hs, p0, p1, g, None, dw_ref, ws)
+        dw, sq = torch.empty(n, device=DEV), torch.full((nsq,), float('nan'), dtype=torch.float64, device=DEV)
+        k.wgrad_batch(dtype, B, [(Hs, Hs, p0, p1, g, None, dw, sq)])
+        assert rel_err(dw, dw_ref.cpu()) <= 1e-5
+        assert abs(float(sq.sum()) - float(dw_ref.double().pow(2).sum())) <= 1e-5 * float(dw_ref.double().pow(2).sum())
+    with pytest.raises(RuntimeError, match='one class per launch'):
+        k.wgrad_batch(dtype, B, [probs[0], (8, 8, torch.zeros(B, 8, 8, 512, device=DEV, dtype=dtype), None,
+                                            torch.zeros(B, 16, 16, 512, device=DEV, dtype=dtype), None,
+                                            torch.empty(512 * 16 * 512, device=DEV), None)])
     Hs = 64
     bad = (Hs, Hs, torch.zeros(B, Hs, Hs, 128, device=DEV, dtype=dtype), None,
            torch.zeros(B, 2 * Hs, 2 * Hs, 64, device=DEV, dtype=dtype), None, torch.empty(128 * 16 * 64, device=DEV), None)
