@@ -98,6 +98,8 @@ _PROTOS = {
     'adn_wgrad_batchable': (c_int32, [C.POINTER(AdnWgradDesc)]),
     'adn_wgrad_batch_sq_count': (c_int32, [C.POINTER(AdnWgradDesc)]),
     'adn_wgrad_batch': (C.c_int, [C.POINTER(AdnWgradDesc), c_int32, c_void_p]),
+    'adn_wgrad_patch_batch_workspace_bytes': (c_int64, [C.POINTER(AdnWgradDesc), c_int32]),
+    'adn_wgrad_patch_batch': (C.c_int, [C.POINTER(AdnWgradDesc), c_int32, c_void_p]),
     'adn_wgrad_sq_count': (c_int32, [C.POINTER(AdnWgradDesc)]),
     'adn_pack_weights': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     'adn_mx8_quantize': (C.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),

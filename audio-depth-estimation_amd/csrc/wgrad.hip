@@ -550,6 +550,8 @@ int adn_wgrad_s1p_launch(const AdnWgradDesc* d, int nsplit, int64_t out_elems, v
 int32_t adn_wgrad_k4_sq_count(const AdnWgradDesc* d);   // wgrad_k4.hip
 int32_t adn_wgrad_k4_batchable(const AdnWgradDesc* d);
 int32_t adn_wgrad_k4_batch_sq_count(const AdnWgradDesc* d);
+int64_t adn_wgrad_k4_patch_batch_workspace_bytes(const AdnWgradDesc* descs, int32_t n);
+int adn_wgrad_k4_patch_batch(const AdnWgradDesc* descs, int32_t n, void* stream);
 int adn_wgrad_k4_batch(const AdnWgradDesc* descs, int32_t n, void* stream);
 
 // Norm partials ride along only in the k4 pair's kernels (the U-Net baseline: 54 M parameters, the gradient pass the
@@ -562,6 +564,16 @@ extern "C" int32_t adn_wgrad_sq_count(const AdnWgradDesc* d) {
 extern "C" int32_t adn_wgrad_batchable(const AdnWgradDesc* d) {
   if (!d || d->geom == ADN_GEMM_S1) return 0;
   return adn_wgrad_k4_batchable(d);
+}
+
+extern "C" int64_t adn_wgrad_patch_batch_workspace_bytes(const AdnWgradDesc* descs, int32_t n) {
+  for (int k = 0; descs && k < n && k < 4; ++k)
+    if (descs[k].geom == ADN_GEMM_S1) return -1;
+  return adn_wgrad_k4_patch_batch_workspace_bytes(descs, n);
+}
+
+extern "C" int adn_wgrad_patch_batch(const AdnWgradDesc* descs, int32_t n, void* stream) {
+  return adn_wgrad_k4_patch_batch(descs, n, stream);
 }
 
 extern "C" int32_t adn_wgrad_batch_sq_count(const AdnWgradDesc* d) {

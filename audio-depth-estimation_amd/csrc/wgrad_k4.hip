@@ -534,6 +534,56 @@ int wrun(const AdnWgradDesc* d, const WPlan& pl, hipStream_t st) {
 bool adn_wgrad_k4p_plan(const AdnWgradDesc* d, int* nsplit, int64_t* out_elems);   // wgrad_s1p.hip (patch-staged kernels)
 int adn_wgrad_k4p_launch(const AdnWgradDesc* d, int nsplit, int64_t out_elems, void* stream);
 
+int adn_wgrad_k4p_batch_launch(const AdnWgradDesc* descs, int n, const int* nsplit, float* const* out, void* stream);
+
+// Patch-staged layers as ONE launch with 1/n of the pixel splits each (n <= 4 layers): per problem the split count of a
+// lone launch divided by n.  Slab regions are laid out back to back in descs[0].workspace.
+namespace {
+bool patch_batch_plan(const AdnWgradDesc* descs, int n, int* ns, int64_t* oe, int64_t* off, int64_t* total) {
+  int64_t at = 0;
+  for (int k = 0; k < n; ++k) {
+    int s1;
+    if (wvalidate(descs + k) != ADN_OK || !adn_wgrad_k4p_plan(descs + k, &s1, &oe[k])) return false;
+    ns[k] = s1 / n > 1 ? s1 / n : 1;
+    off[k] = at;
+    if (ns[k] > 1) at += (int64_t)ns[k] * oe[k] * 4;
+  }
+  *total = at;
+  return true;
+}
+}  // namespace
+
+int64_t adn_wgrad_k4_patch_batch_workspace_bytes(const AdnWgradDesc* descs, int32_t n) {
+  int ns[4];
+  int64_t oe[4], off[4], total;
+  if (!descs || n < 1 || n > 4 || !patch_batch_plan(descs, n, ns, oe, off, &total)) return -1;
+  return total;
+}
+
+int adn_wgrad_k4_patch_batch(const AdnWgradDesc* descs, int32_t n, void* stream) {
+  ADN_CHECK_ARG(descs && n >= 1 && n <= 4, "adn_wgrad_patch_batch: 1 .. 4 problems (got %d)", n);
+  int ns[4];
+  int64_t oe[4], off[4], total;
+  ADN_CHECK_ARG(patch_batch_plan(descs, n, ns, oe, off, &total),
+                "adn_wgrad_patch_batch: a problem is not a patch-staged layer (adn_wgrad_patch_batch_workspace_bytes < 0)");
+  ADN_CHECK_ARG(total == 0 || (descs[0].workspace && descs[0].workspace_bytes >= total),
+                "adn_wgrad_patch_batch: workspace too small (%lld < %lld)", (long long)descs[0].workspace_bytes, (long long)total);
+  float* out[4];
+  for (int k = 0; k < n; ++k)
+    out[k] = ns[k] > 1 ? reinterpret_cast<float*>(reinterpret_cast<char*>(descs[0].workspace) + off[k]) : descs[k].dw;
+  int rc = adn_wgrad_k4p_batch_launch(descs, n, ns, out, stream);
+  if (rc != ADN_OK) return rc;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  for (int k = 0; k < n; ++k) {
+    if (ns[k] <= 1) continue;
+    const int64_t blocks = slab_sum_blocks(oe[k], descs[k].sq_partials != nullptr);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, st, out[k], descs[k].dw, oe[k], ns[k],
+                       descs[k].sq_partials);
+    ADN_CHECK_LAUNCH();
+  }
+  return ADN_OK;
+}
+
 int64_t adn_wgrad_k4_workspace_bytes(const AdnWgradDesc* d) {
   if (wvalidate(d) != ADN_OK) return -1;
   {

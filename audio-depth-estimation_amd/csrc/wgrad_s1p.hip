@@ -239,8 +239,9 @@ struct KParams4 {
 // SPREAD: the next tile's LDS-DMA requests are issued BETWEEN the MFMAs of the current tile (two straight-line regions pinned
 // with sched_group_barrier) instead of in a burst behind the barrier: a request costs the issuing wave ~100 cycles, which the
 // other waves of the SIMD fill with their MFMAs (round 3; the same change was worth 8 ... 20 % in the implicit GEMM)
+// (body shared by the one-problem kernel and the multi-problem launch; `bid` = workgroup index inside its problem)
 template <bool SPREAD>
-__global__ __launch_bounds__(256, 2) void wgrad_k4_patch_kernel(KParams4 p) {
+__device__ __forceinline__ void wgrad_k4_patch_body(const KParams4& p, const int bid) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int TH = 8, TW = 8, PW = 9, PLANE = PW * PW, PPIX = 4 * PLANE;       // 324 patch pixels of 64 bytes
   constexpr int DZBUF = 64 * 128;
@@ -255,8 +256,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_k4_patch_kernel(KParams4 p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nblk = p.nrb * p.ncb;
   const int ngrid = nblk * p.nsplit;
-  const int gq = ngrid >> 3, gr = ngrid & 7, gx = blockIdx.x & 7;
-  const int lid = (gx < gr ? gx * (gq + 1) : gr * (gq + 1) + (gx - gr) * gq) + (blockIdx.x >> 3);
+  const int gq = ngrid >> 3, gr = ngrid & 7, gx = bid & 7;
+  const int lid = (gx < gr ? gx * (gq + 1) : gr * (gq + 1) + (gx - gr) * gq) + (bid >> 3);
   const int blk = lid % nblk, split = lid / nblk;
   const int rb = blk / p.ncb, cb = blk - rb * p.ncb;
   const int r0 = rb * 64, c0 = cb * 32;
@@ -444,6 +445,27 @@ __global__ __launch_bounds__(256, 2) void wgrad_k4_patch_kernel(KParams4 p) {
 #endif
 }
 
+template <bool SPREAD>
+__global__ __launch_bounds__(256, 2) void wgrad_k4_patch_kernel(KParams4 p) {
+  wgrad_k4_patch_body<SPREAD>(p, (int)blockIdx.x);
+}
+
+// Several layers in one launch, each with FEWER pixel splits than a lone launch would take: the slab bytes of a launch are
+// (workgroups x 128 KB) whatever the layer, so three layers sharing 512 workgroups write a third of the slabs each.
+constexpr int kK4BatchMax = 4;
+struct K4Batch {
+  KParams4 p[kK4BatchMax];
+  int first[kK4BatchMax + 1];
+  int n;
+};
+__global__ __launch_bounds__(256, 2) void wgrad_k4_patch_batch_kernel(K4Batch b) {
+  int k = 0;
+#pragma unroll
+  for (int j = 1; j < kK4BatchMax; ++j)
+    if (j < b.n && (int)blockIdx.x >= b.first[j]) k = j;
+  wgrad_k4_patch_body<false>(b.p[k], (int)blockIdx.x - b.first[k]);
+}
+
 // ADN_WGRAD_PATCH=0 switches the patch-staged kernels off; ADN_WGRAD_WGS = workgroups a launch aims at (default 512 = one
 // resident wave of 2 per CU; every workgroup writes its own f32 slab block, so the slab traffic is proportional to it).
 int g_wgs = 512;
@@ -528,6 +550,50 @@ bool adn_wgrad_k4p_plan(const AdnWgradDesc* d, int* nsplit, int64_t* out_elems) 
   *nsplit = ns;
   *out_elems = (int64_t)R * 16 * C;
   return true;
+}
+
+static void fill_k4p(const AdnWgradDesc* d, int nsplit, int64_t out_elems, float* outp, KParams4& p) {
+  p.plain0 = d->plain0;
+  p.plain1 = d->plain1;
+  p.gath0 = d->gath0;
+  p.gath1 = d->gath1;
+  p.R0 = d->R0;
+  p.R1 = d->R1;
+  p.C0 = d->C0;
+  p.C1 = d->C1;
+  p.B = d->B;
+  p.Hs = d->Hs;
+  p.Ws = d->Ws;
+  p.nsplit = nsplit;
+  p.nrb = (d->R0 + d->R1) / 64;
+  p.ncb = (d->C0 + d->C1) / 32;
+  p.tpr = d->Ws / 8;
+  p.tpi = (d->Hs / 8) * p.tpr;
+  p.tiles_total = d->B * p.tpi;
+  p.out = outp;
+  p.out_elems = out_elems;
+}
+
+// n <= 4 problems in one launch; nsplit[k] pixel splits and the slab (or, unsplit, dW) base out[k] per problem
+int adn_wgrad_k4p_batch_launch(const AdnWgradDesc* descs, int n, const int* nsplit, float* const* out, void* stream) {
+  ADN_CHECK_ARG(n >= 1 && n <= kK4BatchMax, "adn_wgrad_patch_batch: 1 .. %d problems", kK4BatchMax);
+  K4Batch b;
+  b.n = n;
+  b.first[0] = 0;
+  for (int k = 0; k < n; ++k) {
+    const AdnWgradDesc* d = descs + k;
+    fill_k4p(d, nsplit[k], (int64_t)(d->R0 + d->R1) * 16 * (d->C0 + d->C1), out[k], b.p[k]);
+    b.first[k + 1] = b.first[k] + b.p[k].nrb * b.p[k].ncb * nsplit[k];
+  }
+  for (int k = n; k < kK4BatchMax; ++k) {
+    b.p[k] = b.p[0];
+    b.first[k + 1] = b.first[n];
+  }
+  constexpr int lds = 2 * (64 * 128 + 24 * 1024);
+  ADN_SET_LDS_ONCE(lds, &wgrad_k4_patch_batch_kernel);
+  hipLaunchKernelGGL(wgrad_k4_patch_batch_kernel, dim3((unsigned)b.first[n]), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), b);
+  ADN_CHECK_LAUNCH();
+  return ADN_OK;
 }
 
 int adn_wgrad_k4p_launch(const AdnWgradDesc* d, int nsplit, int64_t out_elems, void* stream) {

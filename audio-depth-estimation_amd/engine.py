@@ -111,6 +111,9 @@ class UNetEngine(FlatParamEngine):
         if self.edge_path:
             self.cin_pad, self.cout_pad = Cin, cout0
         self.x_nhwc = None if self.edge_path else torch.empty(B, H, W, self.cin_pad, dtype=T, device=dev)
+        batching_patch = (T == torch.bfloat16 and not os.environ.get('ADN_NO_WGRAD_BATCH')
+                          and not os.environ.get('ADN_NO_PATCH_BATCH'))
+        pshape_d, pshape_u = {}, {}
         for i, lv in enumerate(self.levels):
             dw, uw = lv['down'].weight, lv['up'].weight
             cd_in, cd_out = dw.shape[1], dw.shape[0]
@@ -166,6 +169,12 @@ class UNetEngine(FlatParamEngine):
             ws_bytes = max(ws_bytes, w1, w2, w3, w4, w5, w6)
             lv.update(P_d=pd, P_u=pu, P_gu=pgu, P_gd=pgd)
             # small-image levels: their weight gradients ride in one multi-problem launch (adn_wgrad_batch)
+            # patch-staged levels: candidates for the shared-split launch (see _patch_groups below)
+            if batching_patch and not edge0:
+                if cd_in_p == cd_in and K.wgrad_patch_batch_workspace_bytes(T, B, [(hs, wsz, cd_out, 0, cd_in_p, 0)]) >= 0:
+                    pshape_d[i] = (hs, wsz, cd_out, 0, cd_in_p, 0)
+                if cu_out_p == cu_out and K.wgrad_patch_batch_workspace_bytes(T, B, [(hs, wsz, c_up0, c_up1, cu_out_p, 0)]) >= 0:
+                    pshape_u[i] = (hs, wsz, c_up0, c_up1, cu_out_p, 0)
             # (class of the problem -- a launch holds one class -- and its number of norm partials; 0 = own launch)
             batching = T == torch.bfloat16 and not os.environ.get('ADN_NO_WGRAD_BATCH')
             lv['wb_d'], lv['wbq_d'] = (K.wgrad_batchable(T, B, hs, wsz, cd_out, 0, cd_in_p, 0)
@@ -203,6 +212,19 @@ class UNetEngine(FlatParamEngine):
                 w = lv[wk].weight
                 o = lv[wk + '_t2_off']
                 lv[wk + '_t2'] = self.t2_all[o:o + 16 * w.shape[0] * w.shape[1]]
+        # The patch-staged weight gradients of consecutive wide levels share ONE launch with 1/n of the pixel splits each
+        # (adn_wgrad_patch_batch: n layers then write and re-read 1/n of the f32 slabs each): the down group L3, L2, L1 goes
+        # out when L1's output gradient is final, the up group D1, D2, D3 when D3's is.
+        def group(shapes):
+            idx = sorted(shapes)[:4]
+            ok = len(idx) >= 2 and idx == list(range(idx[0], idx[0] + len(idx)))
+            return idx if ok else []
+        self.pb_d, self.pb_u = group(pshape_d), group(pshape_u)
+        self.pshape = {('d', i): pshape_d[i] for i in self.pb_d}
+        self.pshape.update({('u', i): pshape_u[i] for i in self.pb_u})
+        for tag, idx in (('d', self.pb_d), ('u', self.pb_u)):
+            if idx:
+                ws_bytes = max(ws_bytes, K.wgrad_patch_batch_workspace_bytes(T, B, [self.pshape[(tag, i)] for i in idx]))
         self._prepare_fused_norm(B, dev)
         self.t2_table = torch.tensor(rows, dtype=torch.int64, device=dev)
         self.t2_layers, self.t2_blocks = len(rows), blk
@@ -387,6 +409,7 @@ class UNetEngine(FlatParamEngine):
         # (weight gradients of the small-image levels are collected and launched together: nothing inside backward reads
         #  them, and their operands stay untouched until the end of the pass)
         batch = {1: [], 2: []}            # per problem class (kernels.wgrad_batchable)
+        held_u, held_d = [], []           # patch-staged groups (see _prepare: pb_u / pb_d)
         # (the reducer's gradient-ready hook wants every dW as early as possible: the same problems then go out as
         #  one-problem launches of the same kernel form -- unsplit --, so both modes produce identical bits)
         use_batch = self.on_grad_ready is None
@@ -417,7 +440,13 @@ class UNetEngine(FlatParamEngine):
                 self._ready(lv['up'].weight)
                 K.d0_dgrad(dz, self._flat_slice(self.flat_p, lv['up'].weight), B, hs, wsz, segs[0], segs[1])
                 continue
-            if lv['wb_u']:
+            if i in self.pb_u:
+                held_u.append((hs, wsz, in0, in1, dz, None, self._flat_slice(self.flat_g, lv['up'].weight),
+                               lv['up_sq'] if fused_norm else None))
+                if i == self.pb_u[-1]:                    # the group's last (innermost) level: all of them in one launch
+                    K.wgrad_patch_batch(T, B, held_u, ws)
+                    self._ready(lv['up'].weight)
+            elif lv['wb_u']:
                 if len(batch[lv['wb_u']]) == 8:
                     flush(lv['wb_u'])
                 batch[lv['wb_u']].append((hs, wsz, in0, in1, dz, None, self._flat_slice(self.flat_g, lv['up'].weight),
@@ -428,7 +457,8 @@ class UNetEngine(FlatParamEngine):
                 K.wgrad(T, B, hs, wsz, in0, in1, dz, None, self._flat_slice(self.flat_g, lv['up'].weight), ws,
                         c_valid=lv['cu_out'] if (i == 0 and self.cout_pad != lv['cu_out']) else 0,
                         sq=lv['up_sq'] if fused_norm else None)
-            self._ready(lv['up'].weight)
+            if i not in self.pb_u:
+                self._ready(lv['up'].weight)
             K.igemm(T, GEMM_S2, B, hs, wsz, dz, None, lv['up_s2'], lv['cu_in'], EPI_BWD, segs, ws,
                     algo_c=lv['cu_out'])
         # ---- down layers, innermost first
@@ -442,6 +472,12 @@ class UNetEngine(FlatParamEngine):
                 if self._x_in._version != self._x_ver:
                     raise RuntimeError('the network input was modified in place between forward and backward')
                 K.thin_wgrad(self._x_in, lv['Gd'], None, B, hs, wsz, self._flat_slice(self.flat_g, lv['down'].weight), ws)
+            elif i in self.pb_d:
+                flush()
+                held_d.append((hs, wsz, lv['Gd'], None, src, None, self._flat_slice(self.flat_g, lv['down'].weight),
+                               lv['down_sq'] if fused_norm else None))
+                if i == self.pb_d[0]:                     # the group's last (outermost) level
+                    K.wgrad_patch_batch(T, B, held_d, ws)
             elif lv['wb_d']:
                 if len(batch[lv['wb_d']]) == 8:
                     flush(lv['wb_d'])
@@ -455,7 +491,8 @@ class UNetEngine(FlatParamEngine):
                 K.wgrad(T, B, hs, wsz, lv['Gd'], None, src, None, self._flat_slice(self.flat_g, lv['down'].weight), ws,
                         c_valid=lv['cd_in'] if (i == 0 and self.cin_pad != lv['cd_in']) else 0,
                         sq=lv['down_sq'] if fused_norm else None)
-            self._ready(lv['down'].weight)
+            if i not in self.pb_d or i == self.pb_d[0]:
+                self._ready(lv['down'].weight)
             if i > 0:
                 pv = L[i - 1]
                 seg = K.Seg(pv['cd_out'], out0=pv['Gd'], ref=pv['ad'], slope=LEAKY, accumulate=True)

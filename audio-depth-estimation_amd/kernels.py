@@ -194,6 +194,35 @@ def wgrad_batch(dtype, B, problems):
         _prof_end(ev, 'wgrad', flops)
 
 
+def wgrad_patch_batch_workspace_bytes(dtype, B, shapes):
+    """shapes: list of (Hs, Ws, R0, R1, C0, C1).  Bytes of slab scratch of one wgrad_patch_batch launch over them, or -1 when
+    some layer is not a patch-staged one (host-only query)."""
+    arr = (AdnWgradDesc * len(shapes))()
+    for d, (Hs, Ws, R0, R1, C0, C1) in zip(arr, shapes):
+        d.dtype, d.B, d.Hs, d.Ws, d.R0, d.R1, d.C0, d.C1 = dtype_code(dtype), B, Hs, Ws, R0, R1, C0, C1
+        d.plain0 = d.gath0 = d.dw = 1
+        d.plain1 = 1 if R1 else None
+        d.gath1 = 1 if C1 else None
+    return int(_lib.load().adn_wgrad_patch_batch_workspace_bytes(arr, len(shapes)))
+
+
+def wgrad_patch_batch(dtype, B, problems, workspace):
+    """problems: list of (Hs, Ws, plain0, plain1, gath0, gath1, dw, sq): 2 .. 4 patch-staged weight gradients in one launch
+    with 1/n of the pixel splits each (+ one slab sum per problem)."""
+    arr = (AdnWgradDesc * len(problems))()
+    flops = 0.0
+    for slot, (Hs, Ws, p0, p1, g0, g1, dw, sq) in zip(arr, problems):
+        d = _wgrad_desc(dtype, B, Hs, Ws, p0, p1, g0, g1, dw, workspace)
+        d.sq_partials = ptr(sq)
+        C.memmove(C.byref(slot), C.byref(d), C.sizeof(AdnWgradDesc))
+        flops += 2.0 * B * Hs * Ws * (d.R0 + d.R1) * 16 * (d.C0 + d.C1)
+    ev = _prof_begin()
+    _lib.call('adn_wgrad_patch_batch', arr, len(problems), _stream())
+    _lib.annotate(label='wgrad', flops=flops)
+    if ev is not None:
+        _prof_end(ev, 'wgrad', flops)
+
+
 def wgrad_sq_count(dtype, B, Hs, Ws, R0, R1, C0, C1, c_valid=0, ks=0):
     """Partial sums of dW^2 adn_wgrad leaves behind when asked to (``sq=``); 0 = this layer's kernel has no fused form."""
     d = AdnWgradDesc()

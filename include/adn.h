@@ -154,6 +154,13 @@ int adn_wgrad(const AdnWgradDesc* d, void* stream);
 int32_t adn_wgrad_batchable(const AdnWgradDesc* d);
 int32_t adn_wgrad_batch_sq_count(const AdnWgradDesc* d);
 int adn_wgrad_batch(const AdnWgradDesc* descs, int32_t n, void* stream);
+/* 2 .. 4 PATCH-STAGED weight gradients (the levels with >= 16 x 16 images: L1-L3, D1-D3 of unet_256) in ONE launch, each
+ * with 1/n of the pixel splits of a lone launch: the f32 slabs of a launch are (workgroups x 128 KB) whatever the layer,
+ * so n layers sharing the workgroups write and re-read 1/n of the slab bytes each.  Slabs back to back in
+ * descs[0].workspace (adn_wgrad_patch_batch_workspace_bytes; < 0: some problem is not a patch-staged layer); per problem
+ * dW, and sq_partials with adn_wgrad_sq_count entries, as adn_wgrad (equal up to the summation order). */
+int64_t adn_wgrad_patch_batch_workspace_bytes(const AdnWgradDesc* descs, int32_t n);
+int adn_wgrad_patch_batch(const AdnWgradDesc* descs, int32_t n, void* stream);
 /* Number of doubles adn_wgrad writes to d->sq_partials (0: not fused for this descriptor). */
 int32_t adn_wgrad_sq_count(const AdnWgradDesc* d);
 

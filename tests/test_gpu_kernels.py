@@ -340,6 +340,40 @@ def test_epilogue_bwd_two_segments(dtype, shape):
     assert rel_err(from_nhwc(g0), acc_ref) <= 2 * TOL_T_OUT[dtype]
 
 
+@pytest.mark.parametrize('shapes', [[(32, 128, 0, 64), (32, 256, 0, 128)],                      # (Hs, R0, R1, C) at B = 8
+                                    [(64, 128, 0, 64), (32, 256, 0, 128), (32, 512, 0, 256)],
+                                    [(32, 128, 128, 64), (32, 256, 256, 128), (32, 64, 0, 32), (64, 64, 64, 64)]])
+def test_wgrad_patch_batch_against_single_launches(shapes):
+    """adn_wgrad_patch_batch (patch-staged layers in one launch with 1/n of the pixel splits each, then one slab sum per
+    layer) against one adn_wgrad per layer: dW to 1e-5 of its max (another summation order), sums of the norm partials to 1e-6."""
+    k = K()
+    dtype, B = torch.bfloat16, 8
+    torch.manual_seed(23)
+    assert k.wgrad_patch_batch_workspace_bytes(dtype, B, [(h, h, r0, r1, c, 0) for h, r0, r1, c in shapes]) >= 0
+    probs, refs = [], []
+    for Hs, R0, R1, C in shapes:
+        p0 = torch.randn(B, Hs, Hs, R0, device=DEV).to(dtype)
+        p1 = torch.randn(B, Hs, Hs, R1, device=DEV).to(dtype) if R1 else None
+        g = torch.randn(B, 2 * Hs, 2 * Hs, C, device=DEV).to(dtype)
+        n = (R0 + R1) * 16 * C
+        nsq = k.wgrad_sq_count(dtype, B, Hs, Hs, R0, R1, C, 0)
+        ws = torch.empty(max(k.wgrad_workspace_bytes(dtype, B, Hs, Hs, R0, R1, C, 0), 16) // 4, device=DEV)
+        dw_ref = torch.empty(n, device=DEV)
+        sq_ref = torch.zeros(max(nsq, 1), dtype=torch.float64, device=DEV)
+        k.wgrad(dtype, B, Hs, Hs, p0, p1, g, None, dw_ref, ws, sq=sq_ref if nsq else None)
+        dw = torch.full((n,), float('nan'), device=DEV)
+        sq = torch.full((max(nsq, 1),), float('nan'), dtype=torch.float64, device=DEV)
+        probs.append((Hs, Hs, p0, p1, g, None, dw, sq if nsq else None))
+        refs.append((dw_ref, sq_ref, nsq))
+    need = k.wgrad_patch_batch_workspace_bytes(dtype, B, [(h, h, r0, r1, c, 0) for h, r0, r1, c in shapes])
+    ws = torch.empty(max(need, 16) // 4, device=DEV)
+    k.wgrad_patch_batch(dtype, B, probs, ws)
+    for (_, _, _, _, _, _, dw, sq), (dw_ref, sq_ref, nsq) in zip(probs, refs):
+        assert rel_err(dw, dw_ref.cpu()) <= 1e-5
+        if nsq:
+            assert abs(float(sq.sum()) - float(sq_ref.sum())) <= 1e-6 * float(sq_ref.sum())
+
+
 def test_wgrad_batch_equals_single_launches():
     """adn_wgrad_batch (several small-image weight gradients in one launch) is bit-identical to one adn_wgrad per problem,
     dW and the norm partials alike; a problem the unsplit tap-staged kernel does not take is refused."""
